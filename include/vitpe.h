@@ -1,0 +1,155 @@
+/* vitpe.h -- C ABI of libvitpe.so: the MI355X (gfx950) kernels behind the ViT
+ * attention-with-positional-encoding hot path of zhengyk19/vit-rpe-rope.
+ *
+ * The reference is pure Python on ATen ops and has no FFI of its own; the boundary it
+ * exposes is the Python API models.vit.VisionTransformer(...) + --pos_encoding (reference
+ * models/vit.py:148-151, train.py:33-34).  Each entry point below replaces the ATen op
+ * sequence of the cited reference lines; the Python host (vit-rpe-rope_amd/vitpe) binds
+ * them with ctypes and registers them as torch.library custom ops.
+ *
+ * Conventions
+ *  - every function returns a hipError_t as int (0 = success); nothing throws, nothing
+ *    synchronises, nothing allocates: the caller owns every buffer (device pointers);
+ *  - all work is enqueued on `stream` (a hipStream_t passed as void*); re-entrant, no global
+ *    state, capturable into a hipGraph;
+ *  - `dtype` selects the arithmetic/storage type T of activations and GEMM weights:
+ *    VITPE_F32 (exact fp32 MFMA, the 1e-4 parity mode) or VITPE_BF16 (bf16 MFMA, fp32
+ *    accumulate).  LayerNorm/bias/positional parameters, statistics, logits, gradients of
+ *    parameters and optimizer state are always fp32;
+ *  - matrices are dense row-major.
+ */
+#ifndef VITPE_H
+#define VITPE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITPE_F32 0
+#define VITPE_BF16 1
+
+/* --pos_encoding switch, reference train.py:33-34 / models/vit.py:170-196 */
+#define VITPE_PE_NONE 0
+#define VITPE_PE_ABSOLUTE 1
+#define VITPE_PE_RELATIVE 2
+#define VITPE_PE_POLYNOMIAL 3
+#define VITPE_PE_ROPE_AXIAL 4
+#define VITPE_PE_ROPE_MIXED 5
+
+/* gemm_nt epilogues */
+#define VITPE_EPI_BIAS 0      /* C = A W^T + bias                       (attn.qkv / any Linear)        */
+#define VITPE_EPI_BIAS_GELU 1 /* U = A W^T + bias ; C = gelu_erf(U)     (timm Mlp fc1+act, vit.py:118) */
+#define VITPE_EPI_BIAS_RESID 2/* C = A W^T + bias + R                   (attn.proj / fc2 + residual, vit.py:91,122,124) */
+#define VITPE_EPI_PATCH 3     /* patch-embed: row remap + cls row + APE (vit.py:248-258)               */
+#define VITPE_EPI_GELU_BWD 4  /* C = (A W^T) * gelu'(U)                 (autograd of fc1's GELU)       */
+
+typedef void* vitpe_stream_t; /* hipStream_t */
+
+int vitpe_abi_version(void);
+
+/* ---- fused attention (the north-star op) --------------------------------------------------
+ * Replaces reference models/vit.py:47-88 (qkv Linear, head split, RoPE rotate-half on patch
+ * tokens via rope_utils.py:18-37, QK^T*hd^-0.5, + RelativePositionalEncoding /
+ * PolynomialRPE bias (positional_encoding.py:82-95,127-171), softmax, @V, head merge).
+ *   xn    [B,N,D] T   layer-normed tokens (N = patches+1, class token first)
+ *   wqkv  [3D,D]  T   attn.qkv.weight (no bias: Block passes qkv_bias=False, vit.py:110,200)
+ *   out   [B,N,D] T   merged heads, input of attn.proj
+ *   cos/sin: rope-axial [P,HD/2], rope-mixed [H,P,HD/2] contiguous fp32 (else NULL)
+ *   table : relative [H,2N-1] fp32 ; coeff: polynomial [deg+1] or [H,deg+1] fp32 (else NULL)
+ *   grid  : patches per side (sqrt(P)); degree <= 7.
+ * Supported shapes: vitpe_fused_attention_supported() (HD=32, 65<=N<=80, D in {96,192});
+ * anything else returns hipErrorNotSupported.                                              */
+int vitpe_fused_attention_supported(int dtype, int N, int D, int HD);
+int vitpe_fused_attention_fwd(int dtype, const void* xn, const void* wqkv, void* out, int B, int N,
+                              int D, int HD, int mode, const float* cos, const float* sin,
+                              const float* table, const float* coeff, int grid, int degree,
+                              int coeff_per_head, vitpe_stream_t stream);
+/* Backward of the above (the reference relies on autograd).  dqkv [B,N,3D] T is the gradient of
+ * the qkv Linear's output (columns [q|k|v] x heads, like the forward's qkv buffer); the caller
+ * finishes with dxn = dqkv Wqkv (vitpe_gemm_nt on the transposed shadow) and dWqkv = dqkv^T xn
+ * (vitpe_gemm_tn).  dtable / dcoeff / dfreqs are ACCUMULATED into (fp32 atomics).           */
+int vitpe_fused_attention_bwd(int dtype, const void* xn, const void* wqkv, const void* dout,
+                              void* dqkv, int B, int N, int D, int HD, int mode, const float* cos,
+                              const float* sin, const float* table, const float* coeff, int grid,
+                              int degree, int coeff_per_head, float* dtable, float* dcoeff,
+                              float* dfreqs, vitpe_stream_t stream);
+
+/* ---- GEMMs ------------------------------------------------------------------------------
+ * vitpe_gemm_nt: C[M,N] = epi(A[M,K] W[N,K]^T).  nn.Linear forward (vit.py:35,37; timm Mlp
+ * fc1/fc2), nn.Conv2d-as-GEMM patch embed (vit.py:164,248), and -- on a transposed weight
+ * shadow -- the data gradients.  N % 8 == 0; K % 8 == 0 (bf16) / K % 4 == 0 (fp32).
+ *   bias [N] fp32 or NULL; R residual [M,N] T (EPI_BIAS_RESID); U [M,N] T pre-activation
+ *   (written by EPI_BIAS_GELU, read by EPI_GELU_BWD); EPI_PATCH: A = unfolded patches
+ *   [B*P,K], C = tokens [B*(P+1),N], ape [P,N] fp32 or NULL, cls [N] fp32.                 */
+int vitpe_gemm_nt(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
+                  const void* R, void* U, const float* ape, const float* cls, int M, int N, int K,
+                  int P, int Ntok, vitpe_stream_t stream);
+/* vitpe_gemm_tn: dW[N,K] += dY[M,N]^T X[M,K] ; dbias[N] += colsum(dY) (NULL to skip).  fp32
+ * outputs, accumulated with atomics over `splits` token slices.                             */
+int vitpe_gemm_tn(int dtype, const void* dY, const void* X, float* dW, float* dbias, int M, int N,
+                  int K, int splits, vitpe_stream_t stream);
+
+/* ---- LayerNorm (nn.LayerNorm(d), eps 1e-5: vit.py:113,116,210) ------------------------------ */
+int vitpe_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y,
+                        float* mean, float* rstd, int M, int D, float eps, vitpe_stream_t stream);
+int vitpe_layernorm_bwd_blocks(int M); /* workspace = blocks * 2 * D floats */
+/* dx = (dres ? dres : 0) + LN'(dy): also folds the residual-branch gradient of vit.py:122,124 */
+int vitpe_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean,
+                        const float* rstd, const float* gamma, const void* dres, void* dx,
+                        float* dgamma, float* dbeta, float* workspace, int M, int D,
+                        vitpe_stream_t stream);
+int vitpe_reduce_partials(const float* partial, int nparts, int len0, int len1, float* dst0,
+                          float* dst1, vitpe_stream_t stream);
+
+/* ---- patch embed (vit.py:164,245-258) ------------------------------------------------------- */
+/* img [B,C,S,S] fp32 -> patches [B*P, C*p*p] T, column = c*p*p + ky*p + kx                    */
+int vitpe_unfold(int dtype, const float* img, void* patches, int B, int C, int S, int p,
+                 vitpe_stream_t stream);
+/* dcls[d] += sum_b dtok[b,0,d]; dape[p,d] += sum_b dtok[b,1+p,d] (NULL to skip);
+ * dpatch [B*P,D] T = patch rows of dtok (input of the patch-embed weight gradient)            */
+int vitpe_embed_bwd(int dtype, const void* dtok, float* dcls, float* dape, void* dpatch, int B,
+                    int Ntok, int D, vitpe_stream_t stream);
+
+/* ---- positional-encoding tables (models/positional_encoding.py) --------------------------- */
+int vitpe_relative_position_index(long long* out, int L, vitpe_stream_t stream);   /* :67-75, int64 [L,L], bit-exact */
+int vitpe_l1_distance_matrix(long long* out, int G, vitpe_stream_t stream);        /* :136-142, int64 [G*G,G*G], bit-exact */
+int vitpe_rope_axial_tables(const float* inv_freq, float* cosv, float* sinv, int G, int half,
+                            vitpe_stream_t stream);                                /* :228-245 */
+int vitpe_rope_mixed_tables(const float* freqs, float* cosv, float* sinv, int H, int G, int half,
+                            vitpe_stream_t stream);                                /* :325-351 incl. the view-scramble */
+int vitpe_relative_bias(const float* table, float* out, int H, int L, vitpe_stream_t stream); /* :82-95 */
+int vitpe_polynomial_bias(const float* coeff, float* out, int H, int G, int degree, int per_head,
+                          vitpe_stream_t stream);                                  /* :127-171 */
+/* models/rope_utils.py:3-37 on x [B,H,P,HD] fp32 (called once for q, once for k)              */
+int vitpe_apply_rotary(const float* x, float* y, const float* cosv, const float* sinv, int B, int H,
+                       int P, int HD, int per_head, vitpe_stream_t stream);
+
+/* ---- classifier head + loss (vit.py:284-285, train.py:113,119-121,194) -------------------- */
+int vitpe_head_fwd(int dtype, const void* x, const float* gamma, const float* beta, const float* Wh,
+                   const float* bh, float* logits, float* ws_xhat, float* ws_yn, float* ws_rstd,
+                   int B, int Ntok, int D, int Cn, float eps, vitpe_stream_t stream);
+/* out2[0] = mean CE, out2[1] = #correct; dlogits (NULL to skip) = (softmax-onehot)*grad_scale */
+int vitpe_cross_entropy(const float* logits, const long long* labels, float* dlogits, float* out2,
+                        int B, int Cn, float grad_scale, vitpe_stream_t stream);
+int vitpe_head_bwd(int dtype, const float* dlogits, const float* Wh, const float* gamma,
+                   const float* ws_xhat, const float* ws_yn, const float* ws_rstd, float* ws_dyn,
+                   void* dx, float* dWh, float* dbh, float* dgamma, float* dbeta, int B, int Ntok,
+                   int D, int Cn, vitpe_stream_t stream);
+
+/* ---- optimizer + weight shadows (train.py:116,195) ------------------------------------------
+ * hp (device, 16 floats): [0]=lr [1]=beta1 [2]=beta2 [3]=eps [4]=weight_decay [5]=step
+ * [6]=bias_correction1 [7]=bias_correction2 [8]=grad_scale.  The step counter lives on the
+ * device so the call can be replayed from a hipGraph.                                        */
+int vitpe_adamw_step(float* p, float* g, float* m, float* v, void* shadow_bf16, float* hp,
+                     long long n, int zero_grad, vitpe_stream_t stream);
+int vitpe_cast(int dtype, const float* src, void* dst, long long n, vitpe_stream_t stream);
+int vitpe_transpose_cast(int dtype, const float* src, void* dst, int R, int C, vitpe_stream_t stream);
+
+/* ---- primitive self-test (MFMA operand maps, transposed LDS read) ------------------------- */
+int vitpe_selftest_mma(int dtype, const void* A, const void* Bt, const void* Brow, float* C_row,
+                       float* C_tr, vitpe_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITPE_H */

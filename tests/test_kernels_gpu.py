@@ -1,0 +1,360 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (ctypes) against the CPU oracle.
+
+Tolerances (written here, per the parity contract):
+  * integer tables: bit-exact;
+  * fp32 mode (exact-fp32 MFMA): 1e-4 relative (north-star gate; typically ~1e-6);
+  * bf16 mode: 3e-2 relative against the fp32 oracle (bf16 has 8 significant bits).
+"rel" = max|a-b| / max|b| (conftest.rel_err).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import vit_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-4
+BF16_TOL = 3e-2
+DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+
+
+def tol(dt):
+    return F32_TOL if dt == "f32" else BF16_TOL
+
+
+@pytest.fixture(scope="module")
+def K():
+    from vitpe import kernels
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return kernels
+
+
+def dev(t, dtype=None):
+    t = t.cuda()
+    return t.to(dtype).contiguous() if dtype is not None else t.contiguous()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def q(t, dt):
+    """the values the kernel actually sees (bf16-rounded inputs for bf16 mode)"""
+    return t.to(DT[dt]).float()
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_selftest_mma_operand_maps(K, dt):
+    # asymmetric integer data: exact in both types; catches swapped row/col maps
+    g = torch.Generator().manual_seed(1)
+    A = torch.randint(-4, 5, (16, 32), generator=g).float()
+    B = torch.randint(-4, 5, (32, 16), generator=g).float() + torch.arange(16).float()[None, :] * 0.0
+    B[:, 3] += 2.0
+    ref = A @ B
+    c_row, c_tr = K.selftest_mma(dev(A, DT[dt]), dev(B.t().contiguous(), DT[dt]), dev(B, DT[dt]))
+    assert torch.equal(c_row.cpu(), ref), "row-fragment MMA map wrong"
+    assert torch.equal(c_tr.cpu(), ref), "transposed-LDS-read fragment map wrong"
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K_", [(195, 96, 96), (260, 192, 192), (130, 576, 192), (65, 192, 768), (128, 96, 48), (64, 192, 16)])
+def test_gemm_nt_bias(K, dt, M, N, K_):
+    a, w, b = rnd(M, K_, seed=1), rnd(N, K_, seed=2, scale=0.2), rnd(N, seed=3)
+    ref = q(a, dt) @ q(w, dt).t() + b
+    out = K.gemm_nt(dev(a, DT[dt]), dev(w, DT[dt]), dev(b), epi=0)
+    assert rel_err(out.float().cpu(), ref) < tol(dt)
+    out = K.gemm_nt(dev(a, DT[dt]), dev(w, DT[dt]), None, epi=0)
+    assert rel_err(out.float().cpu(), ref - b) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_gemm_nt_gelu_resid_gelubwd(K, dt):
+    M, N, K_ = 195, 384, 96
+    a, w, b = rnd(M, K_, seed=1), rnd(N, K_, seed=2, scale=0.3), rnd(N, seed=3)
+    u_ref = q(a, dt) @ q(w, dt).t() + b
+    h, u = K.gemm_nt(dev(a, DT[dt]), dev(w, DT[dt]), dev(b), epi=1)
+    assert rel_err(u.float().cpu(), u_ref) < tol(dt)
+    assert rel_err(h.float().cpu(), torch.nn.functional.gelu(u_ref)) < tol(dt)
+    r = rnd(M, N, seed=4)
+    out = K.gemm_nt(dev(a, DT[dt]), dev(w, DT[dt]), dev(b), epi=2, resid=dev(r, DT[dt]))
+    assert rel_err(out.float().cpu(), u_ref + q(r, dt)) < tol(dt)
+    # gelu backward epilogue: (A W^T) * gelu'(U)
+    uu = rnd(M, N, seed=5, scale=3.0)
+    ug = q(uu, dt).requires_grad_(True)
+    torch.nn.functional.gelu(ug).sum().backward()
+    out = K.gemm_nt(dev(a, DT[dt]), dev(w, DT[dt]), None, epi=4, u=dev(uu, DT[dt]))
+    assert rel_err(out.float().cpu(), (u_ref - b) * ug.grad) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K_,splits", [(195, 96, 96, 1), (650, 576, 192, 4), (333, 192, 768, 3), (260, 192, 48, 2), (200, 96, 384, 5)])
+def test_gemm_tn_wgrad(K, dt, M, N, K_, splits):
+    dy, x = rnd(M, N, seed=1), rnd(M, K_, seed=2)
+    ref_w = q(dy, dt).t() @ q(x, dt)
+    ref_b = q(dy, dt).sum(0)
+    dw = torch.zeros(N, K_, device="cuda")
+    db = torch.zeros(N, device="cuda")
+    K.gemm_tn(dev(dy, DT[dt]), dev(x, DT[dt]), dw, db, splits=splits)
+    assert rel_err(dw.cpu(), ref_w) < tol(dt)
+    assert rel_err(db.cpu(), ref_b) < tol(dt)
+    K.gemm_tn(dev(dy, DT[dt]), dev(x, DT[dt]), dw, None, splits=splits)  # accumulates
+    assert rel_err(dw.cpu(), 2 * ref_w) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,D", [(195, 192), (67, 96), (33, 768)])
+def test_layernorm_fwd_bwd(K, dt, M, D):
+    x, g, b = rnd(M, D, seed=1, scale=2.0) + 0.3, 1 + 0.1 * rnd(D, seed=2), 0.1 * rnd(D, seed=3)
+    dy, dres = rnd(M, D, seed=4), rnd(M, D, seed=5)
+    xr = q(x, dt).requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5)
+    yr.backward(q(dy, dt))
+    y, mean, rstd = K.layernorm_fwd(dev(x, DT[dt]), dev(g), dev(b))
+    assert rel_err(y.float().cpu(), yr.detach()) < tol(dt)
+    assert rel_err(mean.cpu(), q(x, dt).mean(-1)) < 1e-5
+    dgam = torch.zeros(D, device="cuda")
+    dbet = torch.zeros(D, device="cuda")
+    dx = K.layernorm_bwd(dev(dy, DT[dt]), dev(x, DT[dt]), mean, rstd, dev(g), dgam, dbet, dres=dev(dres, DT[dt]))
+    assert rel_err(dx.float().cpu(), xr.grad + q(dres, dt)) < tol(dt)
+    assert rel_err(dgam.cpu(), gr.grad) < tol(dt)
+    assert rel_err(dbet.cpu(), br.grad) < tol(dt)
+
+
+# ------------------------------------------------------------------------------------------
+ATTN_MODES = ["none", "relative", "polynomial", "polynomial_perhead", "rope-axial", "rope-mixed"]
+
+
+def attn_case(mode, D, H, B, seed=0):
+    """inputs + oracle outputs for the fused attention op (N=65, hd=32)."""
+    N, hd, G = 65, D // H, 8
+    xn = rnd(B, N, D, seed=seed + 1)
+    wqkv = rnd(3 * D, D, seed=seed + 2, scale=0.3)
+    dout = rnd(B, N, D, seed=seed + 3)
+    pe = {}
+    if mode == "relative":
+        pe["table"] = rnd(H, 2 * N - 1, seed=seed + 4, scale=0.5)
+    elif mode.startswith("polynomial"):
+        shp = (4,) if mode == "polynomial" else (H, 4)
+        pe["coeff"] = rnd(*shp, seed=seed + 5, scale=0.4) * torch.tensor([1.0, 1 / 8, 1 / 64, 1 / 512])
+    elif mode == "rope-axial":
+        pe["inv_freq"] = O.rope_axial_inv_freq(hd, 100.0)
+    elif mode == "rope-mixed":
+        pe["freqs"] = rnd(2, H, hd // 2, seed=seed + 6, scale=0.7)
+    return N, hd, G, xn, wqkv, dout, pe
+
+
+def oracle_attn(mode, xn, wqkv, dout, pe, H, dt):
+    N = xn.shape[1]
+    xn_, w_ = q(xn, dt), q(wqkv, dt)
+    leaves = {k: v.clone().requires_grad_(k != "inv_freq") for k, v in pe.items()}
+    freqs_cis = bias = None
+    if mode == "relative":
+        bias = O.relative_bias(leaves["table"], N)
+    elif mode.startswith("polynomial"):
+        bias = O.polynomial_bias(leaves["coeff"], N - 1, H, 3, mode == "polynomial")
+    elif mode == "rope-axial":
+        freqs_cis = O.rope_axial_tables(N - 1, leaves["inv_freq"])
+    elif mode == "rope-mixed":
+        freqs_cis = O.rope_mixed_tables(N - 1, leaves["freqs"])
+    B, _, D = xn.shape
+    hd = D // H
+    qkv = torch.nn.functional.linear(xn_, w_).requires_grad_(True)
+    qkv_h = qkv.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    o = O.attention_core(qkv_h[0], qkv_h[1], qkv_h[2], hd ** -0.5, freqs_cis, bias)
+    out = o.transpose(1, 2).reshape(B, N, D)
+    out.backward(q(dout, dt))
+    grads = {k: v.grad for k, v in leaves.items() if v.requires_grad}
+    return out.detach(), qkv.grad, grads
+
+
+def device_pe(K, mode, pe, H, G):
+    from vitpe.kernels import PETables
+    m = "polynomial" if mode.startswith("polynomial") else mode
+    t = PETables(m, G)
+    if mode == "relative":
+        t.table = dev(pe["table"])
+    elif mode.startswith("polynomial"):
+        t.coeff, t.degree, t.coeff_per_head = dev(pe["coeff"]), 3, mode != "polynomial"
+    elif mode == "rope-axial":
+        t.cos, t.sin = K.rope_axial_tables(dev(pe["inv_freq"]), G)
+    elif mode == "rope-mixed":
+        t.cos, t.sin = K.rope_mixed_tables(dev(pe["freqs"]), G)
+    return t
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ATTN_MODES)
+@pytest.mark.parametrize("D,H,B", [(192, 6, 3), (96, 3, 2)])
+def test_fused_attention_fwd(K, dt, mode, D, H, B):
+    N, hd, G, xn, wqkv, dout, pe = attn_case(mode, D, H, B)
+    ref, _, _ = oracle_attn(mode, xn, wqkv, dout, pe, H, dt)
+    t = device_pe(K, mode, pe, H, G)
+    out = K.fused_attention_fwd(dev(xn, DT[dt]), dev(wqkv, DT[dt]), H, t)
+    assert rel_err(out.float().cpu(), ref) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ATTN_MODES)
+@pytest.mark.parametrize("D,H,B", [(192, 6, 3), (96, 3, 2)])
+def test_fused_attention_bwd(K, dt, mode, D, H, B):
+    N, hd, G, xn, wqkv, dout, pe = attn_case(mode, D, H, B, seed=10)
+    _, dqkv_ref, g_ref = oracle_attn(mode, xn, wqkv, dout, pe, H, dt)
+    t = device_pe(K, mode, pe, H, G)
+    dtab = torch.zeros(H, 2 * N - 1, device="cuda") if mode == "relative" else None
+    dcoef = torch.zeros_like(dev(pe["coeff"])) if mode.startswith("polynomial") else None
+    dfr = torch.zeros(2, H, hd // 2, device="cuda") if mode == "rope-mixed" else None
+    dqkv = K.fused_attention_bwd(dev(xn, DT[dt]), dev(wqkv, DT[dt]), dev(dout, DT[dt]), H, t, dtab, dcoef, dfr)
+    assert rel_err(dqkv.float().cpu(), dqkv_ref) < tol(dt)
+    if mode == "relative":
+        assert rel_err(dtab.cpu(), g_ref["table"]) < tol(dt)
+    if mode.startswith("polynomial"):
+        assert rel_err(dcoef.cpu(), g_ref["coeff"]) < tol(dt)
+    if mode == "rope-mixed":
+        assert rel_err(dfr.cpu(), g_ref["freqs"]) < max(tol(dt), 2e-4)
+
+
+def test_fused_attention_unsupported_shape_is_an_error(K):
+    from vitpe._lib import VitpeError
+    from vitpe.kernels import PETables
+    xn = torch.zeros(1, 17, 64, device="cuda")
+    w = torch.zeros(192, 64, device="cuda")
+    with pytest.raises(VitpeError):
+        K.fused_attention_fwd(xn, w, 2, PETables("none", 4))
+
+
+# ------------------------------------------------------------------------------------------
+def test_integer_tables_bit_exact(K, golden):
+    g = golden("tables")
+    for N in (65, 197):
+        idx = K.relative_position_index(N, "cuda").cpu().numpy()
+        assert idx.dtype == np.int64 and np.array_equal(idx, g[f"rel_index_{N}"])
+        assert np.array_equal(idx, O.relative_position_index(N))
+    for G in (8, 14):
+        l1 = K.l1_distance_matrix(G, "cuda").cpu().numpy()
+        assert l1.dtype == np.int64 and np.array_equal(l1, g[f"l1_{G}"])
+
+
+def test_pe_float_tables_vs_golden(K, golden):
+    g = golden("tables")
+    for hd, P, G in ((32, 64, 8), (64, 196, 14)):
+        cos, sin = K.rope_axial_tables(dev(torch.from_numpy(g[f"axial_inv_freq_hd{hd}"])), G)
+        assert rel_err(cos.cpu(), g[f"axial_cos_hd{hd}_P{P}"]) < 1e-5
+        assert rel_err(sin.cpu(), g[f"axial_sin_hd{hd}_P{P}"]) < 1e-5
+    for H, hd, P, G in ((6, 32, 64, 8), (3, 32, 64, 8), (12, 64, 196, 14)):
+        fr = O.closed_form_tensor("pos_embed.freqs", (2, H, hd // 2))
+        cos, sin = K.rope_mixed_tables(dev(fr), G)
+        assert rel_err(cos.cpu(), g[f"mixed_cos_H{H}_hd{hd}_P{P}"]) < 1e-5
+        assert rel_err(sin.cpu(), g[f"mixed_sin_H{H}_hd{hd}_P{P}"]) < 1e-5
+    tab = O.closed_form_tensor("pos_embed.relative_position_bias_table", (6, 129))
+    assert np.array_equal(K.relative_bias(dev(tab), 65).cpu().numpy(), g["rel_bias_H6_N65"])
+    c = O.closed_form_tensor("pos_embed.coefficients", (4,))
+    assert rel_err(K.polynomial_bias(dev(c), 6, 8, 3, False).cpu(), g["poly_bias_H6_N65_shared"]) < 1e-5
+    c = O.closed_form_tensor("pos_embed.coefficients", (6, 4))
+    assert rel_err(K.polynomial_bias(dev(c), 6, 8, 3, True).cpu(), g["poly_bias_H6_N65_perhead"]) < 1e-5
+
+
+def test_apply_rotary_vs_golden(K, golden):
+    g = golden("rotary")
+    qq = O.closed_form_tensor("rotary.q", (2, 6, 64, 32)) * 20
+    kk = O.closed_form_tensor("rotary.k", (2, 6, 64, 32)) * 20
+    cos, sin = K.rope_axial_tables(dev(O.rope_axial_inv_freq(32, 100.0)), 8)
+    assert rel_err(K.apply_rotary(dev(qq), cos, sin).cpu(), g["axial_q"]) < 1e-5
+    assert rel_err(K.apply_rotary(dev(kk), cos, sin).cpu(), g["axial_k"]) < 1e-5
+    cos, sin = K.rope_mixed_tables(dev(O.closed_form_tensor("pos_embed.freqs", (2, 6, 16))), 8)
+    assert rel_err(K.apply_rotary(dev(qq), cos, sin).cpu(), g["mixed_q"]) < 1e-5
+    assert rel_err(K.apply_rotary(dev(kk), cos, sin).cpu(), g["mixed_k"]) < 1e-5
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("C,S,p", [(3, 32, 4), (1, 32, 4), (3, 224, 16)])
+def test_unfold_and_patch_embed(K, dt, C, S, p):
+    B, D = 3, 96
+    cfg = O.VitConfig(img_size=S, patch_size=p, in_chans=C, embed_dim=D, depth=1, num_heads=3, pos_encoding="absolute")
+    params = O.closed_form_params(cfg)
+    img, _ = O.closed_form_batch(cfg, B)
+    P = cfg.num_patches
+    patches = K.unfold(dev(img), p, DT[dt])
+    g = S // p
+    ref_p = img.reshape(B, C, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(B * P, C * p * p)
+    assert torch.equal(patches.float().cpu(), q(ref_p, dt))
+    pq = {k: v for k, v in params.items()}
+    pq["patch_embed.weight"] = q(params["patch_embed.weight"], dt)
+    ref = O.patch_embed(cfg, pq, q(img, dt))
+    w = dev(params["patch_embed.weight"].reshape(D, -1), DT[dt])
+    ape = dev(params["pos_embed.pos_embed"][0, :P])
+    tok = K.patch_embed_gemm(patches, w, dev(params["patch_embed.bias"]), dev(params["cls_token"].reshape(-1)), ape, B, P)
+    assert rel_err(tok.float().cpu(), ref) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_head_ce_fwd_bwd(K, dt):
+    B, Ntok, D, Cn = 37, 65, 192, 10
+    x = rnd(B, Ntok, D, seed=1, scale=2.0)
+    g, b = 1 + 0.1 * rnd(D, seed=2), 0.1 * rnd(D, seed=3)
+    wh, bh = rnd(Cn, D, seed=4, scale=0.3), rnd(Cn, seed=5, scale=0.1)
+    labels = torch.randint(0, Cn, (B,), generator=torch.Generator().manual_seed(6))
+    xr = q(x, dt).requires_grad_(True)
+    leaves = [t.clone().requires_grad_(True) for t in (g, b, wh, bh)]
+    y = torch.nn.functional.layer_norm(xr, (D,), leaves[0], leaves[1], 1e-5)
+    logits_ref = torch.nn.functional.linear(y[:, 0], leaves[2], leaves[3])
+    loss_ref = torch.nn.functional.cross_entropy(logits_ref, labels)
+    loss_ref.backward()
+    logits, ws = K.head_fwd(dev(x, DT[dt]), dev(g), dev(b), dev(wh), dev(bh), save=True)
+    assert rel_err(logits.cpu(), logits_ref.detach()) < 1e-4
+    out2, dlog = K.cross_entropy(logits, dev(labels))
+    assert abs(float(out2[0]) - float(loss_ref)) < 1e-5
+    assert int(out2[1]) == int((logits_ref.argmax(1) == labels).sum())
+    grads = [torch.zeros_like(dev(t)) for t in (wh, bh, g, b)]
+    dx = K.head_bwd(dlog, dev(wh), dev(g), ws, DT[dt], Ntok, grads[0], grads[1], grads[2], grads[3])
+    assert rel_err(dx.float().cpu(), xr.grad) < tol(dt)
+    assert rel_err(grads[0].cpu(), leaves[2].grad) < 1e-4
+    assert rel_err(grads[1].cpu(), leaves[3].grad) < 1e-4
+    assert rel_err(grads[2].cpu(), leaves[0].grad) < 1e-4
+    assert rel_err(grads[3].cpu(), leaves[1].grad) < 1e-4
+
+
+def test_adamw_matches_oracle(K):
+    n = 10007
+    p0, g0 = rnd(n, seed=1), rnd(n, seed=2, scale=0.1)
+    params, st = {"w": p0.clone()}, O.AdamWState()
+    p = dev(p0.clone())
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    hp = torch.zeros(16, device="cuda")
+    hp[:5] = torch.tensor([1e-3, 0.9, 0.999, 1e-8, 0.01])
+    hp[8] = 1.0
+    shadow = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    for step in range(3):
+        gs = g0 * (step + 1)
+        O.adamw_update(params, {"w": gs}, st)
+        g = dev(gs.clone())
+        K.adamw_step(p, g, m, v, hp, shadow_bf16=shadow, zero_grad=True)
+        assert float(g.abs().max()) == 0.0
+    assert rel_err(p.cpu(), params["w"]) < 1e-6
+    assert torch.equal(shadow.cpu(), p.cpu().to(torch.bfloat16))
+    assert float(hp[5]) == 3.0
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_transpose_cast(K, dt):
+    src = rnd(576, 192, seed=1)
+    out = K.transpose_cast(dev(src), DT[dt])
+    assert torch.equal(out.float().cpu(), q(src, dt).t())
+    assert torch.equal(K.cast(dev(src), DT[dt]).float().cpu(), q(src, dt))
+
+
+def test_embed_bwd(K):
+    B, Ntok, D = 5, 65, 96
+    dtok = rnd(B, Ntok, D, seed=1)
+    dcls = torch.zeros(D, device="cuda")
+    dape = torch.zeros(Ntok - 1, D, device="cuda")
+    dpatch = K.embed_bwd(dev(dtok), dcls, dape)
+    assert rel_err(dcls.cpu(), dtok[:, 0].sum(0)) < 1e-5
+    assert rel_err(dape.cpu(), dtok[:, 1:].sum(0)) < 1e-5
+    assert torch.equal(dpatch.cpu(), dtok[:, 1:].reshape(-1, D))

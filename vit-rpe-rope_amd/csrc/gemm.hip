@@ -1,0 +1,366 @@
+// MFMA GEMMs for the projection / MLP / patch-embed legs of the hot path.
+//
+//  gemm_nt : C[M,N] = epi( A[M,K] * W[N,K]^T )        forward linears and (with a transposed
+//            weight shadow) the data-gradient GEMMs.   Replaces nn.Linear / nn.Conv2d-as-GEMM
+//            (reference models/vit.py:35,37,91,164,248 and timm Mlp fc1/fc2, vit.py:118,124).
+//  gemm_tn : dW[N,K] += dY[M,N]^T * X[M,K]             weight gradients (autograd of the same
+//            linears), contraction over the token dimension, split over M across workgroups.
+//
+// Both are written once over T in {bf16, float} (common.h): bf16 = 16x16x32 MFMA throughput
+// mode, float = exact fp32 16x16x4 MFMA for the 1e-4 parity gate.
+#include "common.h"
+
+namespace vitpe {
+
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2, EPI_PATCH = 3, EPI_GELU_BWD = 4 };
+
+struct GemmNTArgs {
+  const void* A;      // [M,K] T
+  const void* W;      // [N,K] T
+  void* C;            // [M,N] T   (EPI_PATCH: [B*Ntok, N])
+  const float* bias;  // [N] fp32 or null
+  const void* R;      // EPI_BIAS_RESID: residual [M,N] T
+  void* U;            // EPI_BIAS_GELU: pre-activation out [M,N] T ; EPI_GELU_BWD: pre-activation in
+  const float* ape;   // EPI_PATCH: absolute PE rows [P,N] fp32 or null
+  const float* cls;   // EPI_PATCH: class token [N] fp32
+  int M, N, K;
+  int P, Ntok;        // EPI_PATCH: patches per image, tokens per image (P+1)
+};
+
+// Tile: 128 activation rows x 64 weight rows per workgroup, 128 bytes of K per stage,
+// double-buffered in LDS, register-staged global loads (issue early / write late).
+// MFMA orientation is swapped (A-operand = weight rows, B-operand = activation rows) so each
+// lane ends up with 4 consecutive output columns of one row.
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
+  constexpr int BM = 128, BN = 64, ROWB = 144;
+  constexpr int BK = 128 / (int)sizeof(T);  // elements of K per stage (64 bf16 / 32 fp32)
+  constexpr int CPS = BK / 32;              // K32 chunks per stage
+  constexpr int CHN = CH<T>::n;
+  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int EP_LD = BN + 4;             // fp32 epilogue staging row stride
+  static_assert(2 * STAGE >= BM * EP_LD * 4, "epilogue staging must fit in the stage buffers");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int M = a.M, N = a.N, K = a.K;
+  const T* __restrict__ A = reinterpret_cast<const T*>(a.A);
+  const T* __restrict__ W = reinterpret_cast<const T*>(a.W);
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  Chunk16 ra[4], rw[2];
+  const Chunk16 zero = {0u, 0u, 0u, 0u};
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = tid + 256 * i, row = q >> 3, cc = q & 7;
+      const int gm = m0 + row, kk = k0 + cc * CHN;
+      ra[i] = (gm < M && kk < K) ? *reinterpret_cast<const Chunk16*>(A + (size_t)gm * K + kk) : zero;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = tid + 256 * i, row = q >> 3, cc = q & 7;
+      const int gn = n0 + row, kk = k0 + cc * CHN;
+      rw[i] = (gn < N && kk < K) ? *reinterpret_cast<const Chunk16*>(W + (size_t)gn * K + kk) : zero;
+    }
+  };
+  auto sstore = [&](int buf) {
+    unsigned char* sA = smem + buf * STAGE;
+    unsigned char* sW = sA + BM * ROWB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = tid + 256 * i, row = q >> 3, cc = q & 7;
+      *reinterpret_cast<Chunk16*>(sA + row * ROWB + cc * 16) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = tid + 256 * i, row = q >> 3, cc = q & 7;
+      *reinterpret_cast<Chunk16*>(sW + row * ROWB + cc * 16) = rw[i];
+    }
+  };
+
+  const int nk = (K + BK - 1) / BK;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+    const unsigned char* sA = smem + (kt & 1) * STAGE;
+    const unsigned char* sW = sA + BM * ROWB;
+#pragma unroll
+    for (int cs = 0; cs < CPS; ++cs) {
+      Frag<T> fw[4], fa[2];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        fw[nt] = ld_frag(reinterpret_cast<const T*>(sW + (16 * nt + c) * ROWB) + cs * 32 + 8 * g);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        fa[mt] = ld_frag(reinterpret_cast<const T*>(sA + (32 * wave + 16 * mt + c) * ROWB) + cs * 32 + 8 * g);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) mma(fw[nt], fa[mt], acc[nt][mt]);
+    }
+    if (kt + 1 < nk) sstore((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> fp32 LDS tile [m][n] -> coalesced 8-column pieces -------
+  float* ep = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int m = 32 * wave + 16 * mt + c, n = 16 * nt + 4 * g;
+      *reinterpret_cast<f32x4*>(ep + m * EP_LD + n) = acc[nt][mt];
+    }
+  __syncthreads();
+  T* __restrict__ C = reinterpret_cast<T*>(a.C);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = tid + 256 * i, m = q >> 3, n8 = (q & 7) * 8;
+    const int gm = m0 + m, gn = n0 + n8;
+    if (gm >= M || gn >= N) continue;  // N % 8 == 0 is required by the host wrapper
+    float v[8];
+    {
+      f32x4 x = *reinterpret_cast<const f32x4*>(ep + m * EP_LD + n8);
+      f32x4 y = *reinterpret_cast<const f32x4*>(ep + m * EP_LD + n8 + 4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { v[t] = x[t]; v[4 + t] = y[t]; }
+    }
+    if (EPI != EPI_GELU_BWD && a.bias != nullptr) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] += a.bias[gn + t];
+    }
+    size_t orow = (size_t)gm;
+    if (EPI == EPI_PATCH) {
+      const int b = gm / a.P, p = gm - b * a.P;
+      orow = (size_t)b * a.Ntok + 1 + p;
+      if (a.ape != nullptr) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] += a.ape[(size_t)p * N + gn + t];
+      }
+      if (p == 0) {  // class-token row of this image (reference vit.py:253-254; APE skips it)
+        float cv[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) cv[t] = a.cls[gn + t];
+        T* dst = C + (size_t)b * a.Ntok * N + gn;
+#pragma unroll
+        for (int h = 0; h < 8 / CHN; ++h)
+          *reinterpret_cast<Chunk16*>(dst + h * CHN) = f32_to_chunk<T>(cv + h * CHN);
+      }
+    }
+    const size_t off = orow * N + gn;
+    if (EPI == EPI_BIAS_RESID) {
+      const T* R = reinterpret_cast<const T*>(a.R);
+      float rv[8];
+#pragma unroll
+      for (int h = 0; h < 8 / CHN; ++h)
+        chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(R + off + h * CHN), rv + h * CHN);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] += rv[t];
+    }
+    if (EPI == EPI_BIAS_GELU) {
+      T* U = reinterpret_cast<T*>(a.U);
+#pragma unroll
+      for (int h = 0; h < 8 / CHN; ++h)
+        *reinterpret_cast<Chunk16*>(U + off + h * CHN) = f32_to_chunk<T>(v + h * CHN);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = gelu_erf(v[t]);
+    }
+    if (EPI == EPI_GELU_BWD) {
+      const T* U = reinterpret_cast<const T*>(a.U);
+      float uv[8];
+#pragma unroll
+      for (int h = 0; h < 8 / CHN; ++h)
+        chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(U + off + h * CHN), uv + h * CHN);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] *= gelu_erf_grad(uv[t]);
+    }
+#pragma unroll
+    for (int h = 0; h < 8 / CHN; ++h)
+      *reinterpret_cast<Chunk16*>(C + off + h * CHN) = f32_to_chunk<T>(v + h * CHN);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Weight gradient: dW[n][k] += sum_m dY[m][n] * X[m][k]   (+ dbias[n] += sum_m dY[m][n])
+// Tile TN=128 (n) x TK (k) per workgroup, 2x2 waves, RPS token rows per stage staged
+// row-major (as they lie in HBM, coalesced) and consumed through transposed LDS reads.
+// grid = (ceil(N/TN), ceil(K/TK), splits); each z-slice reduces its own token range and
+// adds its partial tile with fp32 atomics (summation order across slices is not fixed).
+struct GemmTNArgs {
+  const void* dY;  // [M,N] T
+  const void* X;   // [M,K] T
+  float* dW;       // [N,K] fp32, accumulated into
+  float* dbias;    // [N] fp32 or null, accumulated into
+  int M, N, K;
+  int rows_per_split;
+};
+
+template <typename T, int TK>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
+  constexpr int TN = 128;
+  constexpr int RPS = 128 / (int)sizeof(T);  // token rows per stage: 64 bf16 / 32 fp32
+  constexpr int CPS = RPS / 32;
+  constexpr int CHN = CH<T>::n;
+  constexpr int LDY = TN + Pad<T>::elems, LDX = TK + Pad<T>::elems;
+  constexpr int YCH = TN / CHN, XCH = TK / CHN;          // 16-B chunks per row
+  constexpr int YIT = RPS * YCH / 256, XIT = RPS * XCH / 256;
+  static_assert(RPS * YCH % 256 == 0 && RPS * XCH % 256 == 0, "stage must divide over 256 threads");
+  constexpr int KT = TK / 32;  // k tiles (16 wide) per wave
+  __shared__ __attribute__((aligned(16))) T sY[RPS * LDY];
+  __shared__ __attribute__((aligned(16))) T sX[RPS * LDX];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int n0 = blockIdx.x * TN, k0 = blockIdx.y * TK;
+  const int M = a.M, N = a.N, K = a.K;
+  const int mbeg = blockIdx.z * a.rows_per_split;
+  const int mend = min(M, mbeg + a.rows_per_split);
+  const T* __restrict__ dY = reinterpret_cast<const T*>(a.dY);
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.X);
+
+  f32x4 acc[4][KT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < KT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  const bool do_bias = (a.dbias != nullptr) && (blockIdx.y == 0);
+  const Chunk16 zero = {0u, 0u, 0u, 0u};
+
+  Chunk16 ry[YIT], rx[XIT];
+  auto gload = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < YIT; ++i) {
+      const int q = tid + 256 * i, row = q / YCH, cc = q % YCH;
+      const int gm = mb + row, gn = n0 + cc * CHN;
+      ry[i] = (gm < mend && gn < N) ? *reinterpret_cast<const Chunk16*>(dY + (size_t)gm * N + gn) : zero;
+    }
+#pragma unroll
+    for (int i = 0; i < XIT; ++i) {
+      const int q = tid + 256 * i, row = q / XCH, cc = q % XCH;
+      const int gm = mb + row, gk = k0 + cc * CHN;
+      rx[i] = (gm < mend && gk < K) ? *reinterpret_cast<const Chunk16*>(X + (size_t)gm * K + gk) : zero;
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < YIT; ++i) {
+      const int q = tid + 256 * i, row = q / YCH, cc = q % YCH;
+      *reinterpret_cast<Chunk16*>(sY + row * LDY + cc * CHN) = ry[i];
+    }
+#pragma unroll
+    for (int i = 0; i < XIT; ++i) {
+      const int q = tid + 256 * i, row = q / XCH, cc = q % XCH;
+      *reinterpret_cast<Chunk16*>(sX + row * LDX + cc * CHN) = rx[i];
+    }
+  };
+
+  if (mbeg < mend) gload(mbeg);
+  for (int mb = mbeg; mb < mend; mb += RPS) {
+    __syncthreads();  // previous stage fully consumed
+    sstore();
+    __syncthreads();
+    if (mb + RPS < mend) gload(mb + RPS);  // next stage in flight under the MFMAs
+#pragma unroll
+    for (int cs = 0; cs < CPS; ++cs) {
+      const int rb0 = cs * 32 + 8 * g, rb1 = rb0 + 4;
+      Frag<T> fy[4], fx[KT];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) fy[nt] = ld_frag_tr(sY, LDY, rb0, rb1, wn * 64 + 16 * nt);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) fx[kt] = ld_frag_tr(sX, LDX, rb0, rb1, wk * (TK / 2) + 16 * kt);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) mma(fy[nt], fx[kt], acc[nt][kt]);
+    }
+    if (do_bias && tid < TN) {
+      float s = 0.f;
+      for (int r = 0; r < RPS; ++r) s += to_f32(sY[r * LDY + tid]);
+      bsum += s;
+    }
+  }
+
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gn = n0 + wn * 64 + 16 * nt + 4 * g + r;
+        const int gk = k0 + wk * (TK / 2) + 16 * kt + c;
+        if (gn < N && gk < K) atomicAdd(a.dW + (size_t)gn * K + gk, acc[nt][kt][r]);
+      }
+  if (do_bias && tid < TN && n0 + tid < N) atomicAdd(a.dbias + n0 + tid, bsum);
+}
+
+}  // namespace vitpe
+
+using namespace vitpe;
+
+template <typename T>
+static int launch_gemm_nt(int epi, const GemmNTArgs& a, hipStream_t s) {
+  dim3 grid((a.M + 127) / 128, (a.N + 63) / 64), block(256);
+  switch (epi) {
+    case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS>), grid, block, 0, s, a); break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS_GELU>), grid, block, 0, s, a); break;
+    case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS_RESID>), grid, block, 0, s, a); break;
+    case EPI_PATCH: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_PATCH>), grid, block, 0, s, a); break;
+    case EPI_GELU_BWD: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_GELU_BWD>), grid, block, 0, s, a); break;
+    default: return (int)hipErrorInvalidValue;
+  }
+  VITPE_CHECK_LAUNCH();
+}
+
+extern "C" int vitpe_gemm_nt(int dtype, int epi, const void* A, const void* W, void* C,
+                             const float* bias, const void* R, void* U, const float* ape,
+                             const float* cls, int M, int N, int K, int P, int Ntok,
+                             hipStream_t stream) {
+  VITPE_REQUIRE(A && W && C && M >= 0 && N > 0 && K > 0);
+  VITPE_REQUIRE(N % 8 == 0);
+  VITPE_REQUIRE(K % (dtype == 1 ? 8 : 4) == 0);
+  VITPE_REQUIRE(dtype == 0 || dtype == 1);
+  if (epi == EPI_BIAS_RESID) VITPE_REQUIRE(R != nullptr);
+  if (epi == EPI_BIAS_GELU || epi == EPI_GELU_BWD) VITPE_REQUIRE(U != nullptr);
+  if (epi == EPI_PATCH) VITPE_REQUIRE(cls != nullptr && P > 0 && Ntok == P + 1 && M % P == 0);
+  if (M == 0) return 0;
+  GemmNTArgs a{A, W, C, bias, R, U, ape, cls, M, N, K, P, Ntok};
+  return dtype == 1 ? launch_gemm_nt<bf16>(epi, a, stream) : launch_gemm_nt<float>(epi, a, stream);
+}
+
+template <typename T>
+static int launch_gemm_tn(GemmTNArgs a, int splits, hipStream_t s) {
+  constexpr int RPS = 128 / (int)sizeof(T);
+  int rps = (a.M + splits - 1) / splits;
+  rps = (rps + RPS - 1) / RPS * RPS;
+  a.rows_per_split = rps;
+  const int nz = (a.M + rps - 1) / rps;
+  dim3 block(256);
+  if (a.K % 128 == 0 || a.K > 192) {
+    dim3 grid((a.N + 127) / 128, (a.K + 127) / 128, nz);
+    hipLaunchKernelGGL((gemm_tn_kernel<T, 128>), grid, block, 0, s, a);
+  } else {
+    dim3 grid((a.N + 127) / 128, (a.K + 63) / 64, nz);
+    hipLaunchKernelGGL((gemm_tn_kernel<T, 64>), grid, block, 0, s, a);
+  }
+  VITPE_CHECK_LAUNCH();
+}
+
+extern "C" int vitpe_gemm_tn(int dtype, const void* dY, const void* X, float* dW, float* dbias,
+                             int M, int N, int K, int splits, hipStream_t stream) {
+  VITPE_REQUIRE(dY && X && dW && M >= 0 && N > 0 && K > 0 && splits >= 1);
+  VITPE_REQUIRE(dtype == 0 || dtype == 1);
+  VITPE_REQUIRE(N % (dtype == 1 ? 8 : 4) == 0 && K % (dtype == 1 ? 8 : 4) == 0);
+  if (M == 0) return 0;
+  GemmTNArgs a{dY, X, dW, dbias, M, N, K, 0};
+  return dtype == 1 ? launch_gemm_tn<bf16>(a, splits, stream) : launch_gemm_tn<float>(a, splits, stream);
+}

@@ -1,0 +1,476 @@
+// Patch-embed unfold, positional-encoding table builders, stand-alone rotary apply, classifier
+// head + cross-entropy, fused AdamW with weight shadows, and the primitive self-tests.
+#include "common.h"
+
+namespace vitpe {
+
+// ---------------------------------------------------------------------------------------
+// Patch-embed unfold (reference models/vit.py:164,248-250: Conv2d(k=s=p) == unfold + GEMM).
+// patches[(b*P + gy*g + gx)][c*p*p + ky*p + kx] = img[b][c][gy*p+ky][gx*p+kx]
+// One thread per (b, patch, c, ky) moves p contiguous pixels (fp32 in, T out).
+template <typename T>
+__global__ void unfold_kernel(const float* __restrict__ img, T* __restrict__ patches, int B, int Cc, int S, int p) {
+  const int g = S / p, P = g * g, Kp = Cc * p * p;
+  const long long total = (long long)B * P * Cc * p;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int ky = (int)(idx % p);
+    long long t = idx / p;
+    const int ch = (int)(t % Cc); t /= Cc;
+    const int n = (int)(t % P);
+    const int b = (int)(t / P);
+    const int gy = n / g, gx = n % g;
+    const float* src = img + (((size_t)b * Cc + ch) * S + gy * p + ky) * S + gx * p;
+    T* dst = patches + ((size_t)b * P + n) * Kp + ch * p * p + ky * p;
+    for (int kx = 0; kx < p; ++kx) dst[kx] = from_f32<T>(src[kx]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Integer tables (bit-exact contract)
+__global__ void rel_index_kernel(long long* out, int L) {  // positional_encoding.py:67-75
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= L * L) return;
+  const int i = idx / L, j = idx % L;
+  long long v = (long long)i - j + (L - 1);
+  v = v < 0 ? 0 : (v > 2LL * L - 2 ? 2LL * L - 2 : v);
+  out[idx] = v;
+}
+__global__ void l1_matrix_kernel(long long* out, int G) {  // positional_encoding.py:136-142
+  const int P = G * G;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P * P) return;
+  const int i = idx / P, j = idx % P;
+  out[idx] = (long long)(abs(i % G - j % G) + abs(i / G - j / G));
+}
+
+// RoPE tables.  axial: phase[n][f] = (f < q ? n%G : n/G) * inv_freq[f mod q]   (positional_encoding.py:228-245)
+__global__ void rope_axial_kernel(const float* __restrict__ inv_freq, float* cosv, float* sinv, int G, int half) {
+  const int P = G * G, q = half / 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P * half) return;
+  const int n = idx / half, f = idx % half;
+  const float t = (f < q) ? (float)(n % G) : (float)(n / G);
+  const float ph = __fmul_rn(t, inv_freq[f < q ? f : f - q]);
+  cosv[idx] = cosf(ph);
+  sinv[idx] = sinf(ph);
+}
+// mixed: slot [h,n] = phase of head (n*H+h)/P at position (n*H+h)%P -- the reference's
+// view-scramble (positional_encoding.py:337-342).  Output contiguous [H,P,half].
+__global__ void rope_mixed_kernel(const float* __restrict__ freqs, float* cosv, float* sinv, int H, int G, int half) {
+  const int P = G * G;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= H * P * half) return;
+  const int f = idx % half, n = (idx / half) % P, h = idx / (half * P);
+  const int flat = n * H + h, hs = flat / P, ps = flat % P;
+  const float tx = (float)(ps % G), ty = (float)(ps / G);
+  const float ph = __fadd_rn(__fmul_rn(tx, freqs[(0 * H + hs) * half + f]), __fmul_rn(ty, freqs[(1 * H + hs) * half + f]));
+  cosv[idx] = cosf(ph);
+  sinv[idx] = sinf(ph);
+}
+
+// bias[h,i,j] materialised for the get_bias() API surface (positional_encoding.py:82-95, 127-171)
+__global__ void rel_bias_kernel(const float* __restrict__ table, float* out, int H, int L) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= H * L * L) return;
+  const int j = idx % L, i = (idx / L) % L, h = idx / (L * L);
+  int r = i - j + L - 1;
+  r = max(0, min(r, 2 * L - 2));
+  out[idx] = table[h * (2 * L - 1) + r];
+}
+__global__ void poly_bias_kernel(const float* __restrict__ coeff, float* out, int H, int G, int degree, int per_head) {
+  const int P = G * G, L = P + 1;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= H * L * L) return;
+  const int j = idx % L, i = (idx / L) % L, h = idx / (L * L);
+  float v = 0.f;
+  if (i >= 1 && j >= 1) {
+    const int pi = i - 1, pj = j - 1;
+    const float x = (float)(abs(pi % G - pj % G) + abs(pi / G - pj / G));
+    const float* cf = coeff + (per_head ? h * (degree + 1) : 0);
+    float pw = 1.f;  // sum_k c_k * x^k in ascending k like the reference's feats @ coeffs
+    for (int k = 0; k <= degree; ++k) { v += pw * cf[k]; pw *= x; }
+  }
+  out[idx] = v;
+}
+
+// stand-alone rotate-half (models/rope_utils.py:3-37): x [B,H,P,HD] fp32, cos/sin [P,HD/2] or [H,P,HD/2]
+__global__ void rotary_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ cosv,
+                              const float* __restrict__ sinv, long long total_pairs, int H, int P, int half, int per_head) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total_pairs) return;
+  const int f = (int)(idx % half);
+  long long t = idx / half;
+  const int n = (int)(t % P); t /= P;
+  const int h = (int)(t % H);
+  const size_t row = (size_t)(idx / half) * 2 * half;
+  const size_t o = ((per_head ? (size_t)h * P : 0) + n) * half + f;
+  const float c = cosv[o], s = sinv[o];
+  const float x1 = x[row + f], x2 = x[row + half + f];
+  y[row + f] = __fsub_rn(__fmul_rn(x1, c), __fmul_rn(x2, s));
+  y[row + half + f] = __fadd_rn(__fmul_rn(x1, s), __fmul_rn(x2, c));
+}
+
+// ---------------------------------------------------------------------------------------
+// Classifier head (vit.py:284-285): LayerNorm of the class row only, then Linear(d, classes).
+// One wave per image.  ws_* (optional, for backward): xhat [B,D], yn [B,D] fp32.
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ Wh,
+                                                       const float* __restrict__ bh, float* __restrict__ logits,
+                                                       float* __restrict__ ws_xhat, float* __restrict__ ws_yn,
+                                                       float* __restrict__ ws_rstd, int B, int Ntok, int D, int Cn,
+                                                       float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invD = 1.0f / (float)D;
+  for (int b = blockIdx.x * 4 + wave; b < B; b += gridDim.x * 4) {
+    const T* row = x + (size_t)b * Ntok * D;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += to_f32(row[d]);
+    const float mean = wave_sum(s) * invD;
+    float s2 = 0.f;
+    for (int d = lane; d < D; d += 64) { const float t = to_f32(row[d]) - mean; s2 += t * t; }
+    const float rstd = 1.0f / sqrtf(wave_sum(s2) * invD + eps);
+    for (int cI = 0; cI < Cn; ++cI) {
+      float acc = 0.f;
+      for (int d = lane; d < D; d += 64) {
+        const float xh = (to_f32(row[d]) - mean) * rstd;
+        acc += (xh * gamma[d] + beta[d]) * Wh[(size_t)cI * D + d];
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) logits[(size_t)b * Cn + cI] = acc + bh[cI];
+    }
+    if (ws_xhat) {
+      for (int d = lane; d < D; d += 64) {
+        const float xh = (to_f32(row[d]) - mean) * rstd;
+        ws_xhat[(size_t)b * D + d] = xh;
+        ws_yn[(size_t)b * D + d] = xh * gamma[d] + beta[d];
+      }
+      if (lane == 0) ws_rstd[b] = rstd;
+    }
+  }
+}
+
+// mean cross-entropy + dlogits = (softmax - onehot) * gscale ; single workgroup, fixed order.
+// out[0] = mean loss, out[1] = #correct (argmax == label)   (train.py:113,119-121)
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                                                 float* __restrict__ dlogits, float* __restrict__ out, int B, int Cn,
+                                                 float gscale) {
+  __shared__ float sl[256], sc[256];
+  float lsum = 0.f, csum = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float* z = logits + (size_t)b * Cn;
+    float m = z[0];
+    int am = 0;
+    for (int k = 1; k < Cn; ++k) if (z[k] > m) { m = z[k]; am = k; }
+    float se = 0.f;
+    for (int k = 0; k < Cn; ++k) se += expf(z[k] - m);
+    const int y = (int)labels[b];
+    lsum += (m + logf(se)) - z[y];
+    csum += (am == y) ? 1.f : 0.f;
+    if (dlogits) {
+      const float inv = 1.0f / se;
+      for (int k = 0; k < Cn; ++k) dlogits[(size_t)b * Cn + k] = (expf(z[k] - m) * inv - (k == y ? 1.f : 0.f)) * gscale;
+    }
+  }
+  sl[threadIdx.x] = lsum;
+  sc[threadIdx.x] = csum;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = sl[0] / (float)B; out[1] = sc[0]; }
+}
+
+// head backward, stage 1 (one wave per image): dyn = dlogits @ Wh ; LN backward of the class row;
+// dx row 0 written, rows 1.. zeroed.  ws_dyn [B,D] kept for stage 2.
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_rows_kernel(const float* __restrict__ dlogits, const float* __restrict__ Wh,
+                                                            const float* __restrict__ gamma, const float* __restrict__ ws_xhat,
+                                                            const float* __restrict__ ws_rstd, float* __restrict__ ws_dyn,
+                                                            T* __restrict__ dx, int B, int Ntok, int D, int Cn) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invD = 1.0f / (float)D;
+  for (int b = blockIdx.x * 4 + wave; b < B; b += gridDim.x * 4) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int d = lane; d < D; d += 64) {
+      float dyn = 0.f;
+      for (int k = 0; k < Cn; ++k) dyn += dlogits[(size_t)b * Cn + k] * Wh[(size_t)k * D + d];
+      ws_dyn[(size_t)b * D + d] = dyn;
+      const float gv = dyn * gamma[d];
+      s1 += gv;
+      s2 += gv * ws_xhat[(size_t)b * D + d];
+    }
+    s1 = wave_sum(s1) * invD;
+    s2 = wave_sum(s2) * invD;
+    const float rstd = ws_rstd[b];
+    T* drow = dx + (size_t)b * Ntok * D;
+    for (int d = lane; d < D; d += 64) {
+      const float gv = ws_dyn[(size_t)b * D + d] * gamma[d];
+      drow[d] = from_f32<T>(rstd * (gv - s1 - ws_xhat[(size_t)b * D + d] * s2));
+    }
+    for (size_t q = D + lane; q < (size_t)Ntok * D; q += 64) drow[q] = from_f32<T>(0.f);
+  }
+}
+// stage 2: column sums over the batch in a fixed order.
+//   dWh[k][d] += sum_b dlogits[b][k]*yn[b][d] ; dbh[k] += sum_b dlogits[b][k]
+//   dgamma[d] += sum_b dyn*xhat ; dbeta[d] += sum_b dyn
+__global__ void head_bwd_params_kernel(const float* __restrict__ dlogits, const float* __restrict__ ws_yn,
+                                       const float* __restrict__ ws_dyn, const float* __restrict__ ws_xhat,
+                                       float* dWh, float* dbh, float* dgamma, float* dbeta, int B, int D, int Cn) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nW = Cn * D;
+  if (idx < nW) {
+    const int k = idx / D, d = idx % D;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dlogits[(size_t)b * Cn + k] * ws_yn[(size_t)b * D + d];
+    dWh[idx] += s;
+  } else if (idx < nW + Cn) {
+    const int k = idx - nW;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dlogits[(size_t)b * Cn + k];
+    dbh[k] += s;
+  } else if (idx < nW + Cn + D) {
+    const int d = idx - nW - Cn;
+    float sg = 0.f, sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float dy = ws_dyn[(size_t)b * D + d];
+      sg += dy * ws_xhat[(size_t)b * D + d];
+      sb += dy;
+    }
+    dgamma[d] += sg;
+    dbeta[d] += sb;
+  }
+}
+
+// patch-embed parameter gradients that are plain column sums of the token gradient:
+//   dcls[d] += sum_b dtok[b,0,d] ; dape[p][d] += sum_b dtok[b,1+p,d]   (vit.py:253-258)
+// and repacking of the patch-token gradient rows into the GEMM layout [B*P, D]
+template <typename T>
+__global__ void embed_bwd_kernel(const T* __restrict__ dtok, float* dcls, float* dape, T* __restrict__ dpatch,
+                                 int B, int Ntok, int D) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over Ntok*D
+  if (idx >= Ntok * D) return;
+  const int n = idx / D, d = idx % D;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const T v = dtok[((size_t)b * Ntok + n) * D + d];
+    s += to_f32(v);
+    if (n >= 1) dpatch[((size_t)b * (Ntok - 1) + n - 1) * D + d] = v;
+  }
+  if (n == 0) dcls[d] += s;
+  else if (dape) dape[(size_t)(n - 1) * D + d] += s;
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused AdamW over the flat fp32 parameter / gradient / moment buffers (train.py:195:
+// one param group, decoupled weight decay on everything) + bf16 weight shadow + grad reset.
+// hp (device): [0]=lr [1]=beta1 [2]=beta2 [3]=eps [4]=weight_decay [5]=step [6]=bc1 [7]=bc2 [8]=grad_scale
+__global__ void adamw_tick_kernel(float* hp) {
+  const float step = hp[5] + 1.0f;
+  hp[5] = step;
+  hp[6] = 1.0f - powf(hp[1], step);
+  hp[7] = 1.0f - powf(hp[2], step);
+}
+__global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             bf16* __restrict__ shadow, const float* __restrict__ hp, long long n, int zero_grad) {
+  const float lr = hp[0], b1 = hp[1], b2 = hp[2], eps = hp[3], wd = hp[4], bc1 = hp[6], bc2 = hp[7], gs = hp[8];
+  const float inv_sqrt_bc2 = 1.0f / sqrtf(bc2), step_size = lr / bc1;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gs;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+    if (shadow) shadow[i] = (bf16)pi;
+    if (zero_grad) g[i] = 0.f;
+  }
+}
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    dst[i] = from_f32<T>(src[i]);
+}
+// dst[c][r] = (T) src[r][c]  -- transposed weight shadows for the data-gradient GEMMs
+template <typename T>
+__global__ void transpose_cast_kernel(const float* __restrict__ src, T* __restrict__ dst, int R, int Cc) {
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    tile[i][threadIdx.x] = (r < R && c < Cc) ? src[(size_t)r * Cc + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (c < Cc && r < R) dst[(size_t)c * R + r] = from_f32<T>(tile[threadIdx.x][i]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Self-tests of the primitives every kernel relies on (run by tests/ on the GPU box):
+//  C[16x16] = A[16x32] * B[32x16] through mma<T>, with A given row-major [16][32] and B either
+//  as B^T row-major [16][32] (row fragments) or as B row-major [32][16] read through ld_frag_tr.
+template <typename T>
+__global__ void selftest_mma_kernel(const T* __restrict__ A, const T* __restrict__ Bt, const T* __restrict__ Brow,
+                                    float* __restrict__ C_row, float* __restrict__ C_tr) {
+  __shared__ __attribute__((aligned(16))) T sB[32 * 24];  // row-major [32][16], ld 24
+  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+  for (int q = lane; q < 32 * 16; q += 64) sB[(q / 16) * 24 + (q % 16)] = Brow[q];
+  __syncthreads();
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  mma(ld_frag(A + c * 32 + 8 * g), ld_frag(Bt + c * 32 + 8 * g), acc);
+  for (int r = 0; r < 4; ++r) C_row[(4 * g + r) * 16 + c] = acc[r];
+  f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+  mma(ld_frag(A + c * 32 + 8 * g), ld_frag_tr(sB, 24, 8 * g, 8 * g + 4, 0), acc2);
+  for (int r = 0; r < 4; ++r) C_tr[(4 * g + r) * 16 + c] = acc2[r];
+}
+
+}  // namespace vitpe
+
+using namespace vitpe;
+
+#define GRID1D(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256)
+
+extern "C" int vitpe_unfold(int dtype, const float* img, void* patches, int B, int C, int S, int p, hipStream_t st) {
+  VITPE_REQUIRE(img && patches && B >= 0 && C > 0 && p > 0 && S % p == 0 && (dtype == 0 || dtype == 1));
+  const long long total = (long long)B * (S / p) * (S / p) * C * p;
+  if (total == 0) return 0;
+  const unsigned blocks = (unsigned)min((total + 255) / 256, (long long)8192);
+  if (dtype == 1) hipLaunchKernelGGL(unfold_kernel<bf16>, dim3(blocks), dim3(256), 0, st, img, (bf16*)patches, B, C, S, p);
+  else hipLaunchKernelGGL(unfold_kernel<float>, dim3(blocks), dim3(256), 0, st, img, (float*)patches, B, C, S, p);
+  VITPE_CHECK_LAUNCH();
+}
+
+extern "C" int vitpe_relative_position_index(long long* out, int L, hipStream_t st) {
+  VITPE_REQUIRE(out && L > 0);
+  hipLaunchKernelGGL(rel_index_kernel, GRID1D(L * L), 0, st, out, L);
+  VITPE_CHECK_LAUNCH();
+}
+extern "C" int vitpe_l1_distance_matrix(long long* out, int G, hipStream_t st) {
+  VITPE_REQUIRE(out && G > 0);
+  hipLaunchKernelGGL(l1_matrix_kernel, GRID1D(G * G * G * G), 0, st, out, G);
+  VITPE_CHECK_LAUNCH();
+}
+extern "C" int vitpe_rope_axial_tables(const float* inv_freq, float* cosv, float* sinv, int G, int half, hipStream_t st) {
+  VITPE_REQUIRE(inv_freq && cosv && sinv && G > 0 && half > 0 && half % 2 == 0);
+  hipLaunchKernelGGL(rope_axial_kernel, GRID1D(G * G * half), 0, st, inv_freq, cosv, sinv, G, half);
+  VITPE_CHECK_LAUNCH();
+}
+extern "C" int vitpe_rope_mixed_tables(const float* freqs, float* cosv, float* sinv, int H, int G, int half, hipStream_t st) {
+  VITPE_REQUIRE(freqs && cosv && sinv && H > 0 && G > 0 && half > 0);
+  hipLaunchKernelGGL(rope_mixed_kernel, GRID1D(H * G * G * half), 0, st, freqs, cosv, sinv, H, G, half);
+  VITPE_CHECK_LAUNCH();
+}
+extern "C" int vitpe_relative_bias(const float* table, float* out, int H, int L, hipStream_t st) {
+  VITPE_REQUIRE(table && out && H > 0 && L > 0);
+  hipLaunchKernelGGL(rel_bias_kernel, GRID1D(H * L * L), 0, st, table, out, H, L);
+  VITPE_CHECK_LAUNCH();
+}
+extern "C" int vitpe_polynomial_bias(const float* coeff, float* out, int H, int G, int degree, int per_head, hipStream_t st) {
+  VITPE_REQUIRE(coeff && out && H > 0 && G > 0 && degree >= 0);
+  const int L = G * G + 1;
+  hipLaunchKernelGGL(poly_bias_kernel, GRID1D(H * L * L), 0, st, coeff, out, H, G, degree, per_head);
+  VITPE_CHECK_LAUNCH();
+}
+extern "C" int vitpe_apply_rotary(const float* x, float* y, const float* cosv, const float* sinv, int B, int H, int P,
+                                  int HD, int per_head, hipStream_t st) {
+  VITPE_REQUIRE(x && y && cosv && sinv && B >= 0 && H > 0 && P > 0 && HD > 0 && HD % 2 == 0);
+  const long long total = (long long)B * H * P * (HD / 2);
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(rotary_kernel, GRID1D(total), 0, st, x, y, cosv, sinv, total, H, P, HD / 2, per_head);
+  VITPE_CHECK_LAUNCH();
+}
+
+extern "C" int vitpe_head_fwd(int dtype, const void* x, const float* gamma, const float* beta, const float* Wh,
+                              const float* bh, float* logits, float* ws_xhat, float* ws_yn, float* ws_rstd, int B,
+                              int Ntok, int D, int Cn, float eps, hipStream_t st) {
+  VITPE_REQUIRE(x && gamma && beta && Wh && bh && logits && B >= 0 && (dtype == 0 || dtype == 1));
+  VITPE_REQUIRE((ws_xhat == nullptr) == (ws_yn == nullptr) && (ws_xhat == nullptr) == (ws_rstd == nullptr));
+  if (B == 0) return 0;
+  const int blocks = min((B + 3) / 4, 1024);
+  if (dtype == 1)
+    hipLaunchKernelGGL(head_fwd_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)x, gamma, beta, Wh, bh,
+                       logits, ws_xhat, ws_yn, ws_rstd, B, Ntok, D, Cn, eps);
+  else
+    hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, gamma, beta, Wh, bh,
+                       logits, ws_xhat, ws_yn, ws_rstd, B, Ntok, D, Cn, eps);
+  VITPE_CHECK_LAUNCH();
+}
+extern "C" int vitpe_cross_entropy(const float* logits, const long long* labels, float* dlogits, float* out2, int B,
+                                   int Cn, float grad_scale, hipStream_t st) {
+  VITPE_REQUIRE(logits && labels && out2 && B > 0 && Cn > 0);
+  hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(256), 0, st, logits, labels, dlogits, out2, B, Cn, grad_scale);
+  VITPE_CHECK_LAUNCH();
+}
+extern "C" int vitpe_head_bwd(int dtype, const float* dlogits, const float* Wh, const float* gamma,
+                              const float* ws_xhat, const float* ws_yn, const float* ws_rstd, float* ws_dyn, void* dx,
+                              float* dWh, float* dbh, float* dgamma, float* dbeta, int B, int Ntok, int D, int Cn,
+                              hipStream_t st) {
+  VITPE_REQUIRE(dlogits && Wh && gamma && ws_xhat && ws_yn && ws_rstd && ws_dyn && dx && dWh && dbh && dgamma && dbeta);
+  VITPE_REQUIRE(B >= 0 && (dtype == 0 || dtype == 1));
+  if (B == 0) return 0;
+  const int blocks = min((B + 3) / 4, 1024);
+  if (dtype == 1)
+    hipLaunchKernelGGL(head_bwd_rows_kernel<bf16>, dim3(blocks), dim3(256), 0, st, dlogits, Wh, gamma, ws_xhat,
+                       ws_rstd, ws_dyn, (bf16*)dx, B, Ntok, D, Cn);
+  else
+    hipLaunchKernelGGL(head_bwd_rows_kernel<float>, dim3(blocks), dim3(256), 0, st, dlogits, Wh, gamma, ws_xhat,
+                       ws_rstd, ws_dyn, (float*)dx, B, Ntok, D, Cn);
+  int e = (int)hipGetLastError();
+  if (e) return e;
+  hipLaunchKernelGGL(head_bwd_params_kernel, GRID1D(Cn * D + Cn + D), 0, st, dlogits, ws_yn, ws_dyn, ws_xhat, dWh,
+                     dbh, dgamma, dbeta, B, D, Cn);
+  VITPE_CHECK_LAUNCH();
+}
+extern "C" int vitpe_embed_bwd(int dtype, const void* dtok, float* dcls, float* dape, void* dpatch, int B, int Ntok,
+                               int D, hipStream_t st) {
+  VITPE_REQUIRE(dtok && dcls && dpatch && B >= 0 && (dtype == 0 || dtype == 1));
+  if (dtype == 1)
+    hipLaunchKernelGGL(embed_bwd_kernel<bf16>, GRID1D(Ntok * D), 0, st, (const bf16*)dtok, dcls, dape, (bf16*)dpatch, B, Ntok, D);
+  else
+    hipLaunchKernelGGL(embed_bwd_kernel<float>, GRID1D(Ntok * D), 0, st, (const float*)dtok, dcls, dape, (float*)dpatch, B, Ntok, D);
+  VITPE_CHECK_LAUNCH();
+}
+
+extern "C" int vitpe_adamw_step(float* p, float* g, float* m, float* v, void* shadow_bf16, float* hp, long long n,
+                                int zero_grad, hipStream_t st) {
+  VITPE_REQUIRE(p && g && m && v && hp && n >= 0);
+  hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, st, hp);
+  if (n > 0) {
+    const unsigned blocks = (unsigned)min((n + 255) / 256, (long long)4096);
+    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, (bf16*)shadow_bf16, hp, n, zero_grad);
+  }
+  VITPE_CHECK_LAUNCH();
+}
+extern "C" int vitpe_cast(int dtype, const float* src, void* dst, long long n, hipStream_t st) {
+  VITPE_REQUIRE(src && dst && n >= 0 && (dtype == 0 || dtype == 1));
+  if (n == 0) return 0;
+  const unsigned blocks = (unsigned)min((n + 255) / 256, (long long)4096);
+  if (dtype == 1) hipLaunchKernelGGL(cast_kernel<bf16>, dim3(blocks), dim3(256), 0, st, src, (bf16*)dst, n);
+  else hipLaunchKernelGGL(cast_kernel<float>, dim3(blocks), dim3(256), 0, st, src, (float*)dst, n);
+  VITPE_CHECK_LAUNCH();
+}
+extern "C" int vitpe_transpose_cast(int dtype, const float* src, void* dst, int R, int C, hipStream_t st) {
+  VITPE_REQUIRE(src && dst && R > 0 && C > 0 && (dtype == 0 || dtype == 1));
+  dim3 grid((C + 31) / 32, (R + 31) / 32), block(32, 8);
+  if (dtype == 1) hipLaunchKernelGGL(transpose_cast_kernel<bf16>, grid, block, 0, st, src, (bf16*)dst, R, C);
+  else hipLaunchKernelGGL(transpose_cast_kernel<float>, grid, block, 0, st, src, (float*)dst, R, C);
+  VITPE_CHECK_LAUNCH();
+}
+
+extern "C" int vitpe_selftest_mma(int dtype, const void* A, const void* Bt, const void* Brow, float* C_row, float* C_tr,
+                                  hipStream_t st) {
+  VITPE_REQUIRE(A && Bt && Brow && C_row && C_tr && (dtype == 0 || dtype == 1));
+  if (dtype == 1)
+    hipLaunchKernelGGL(selftest_mma_kernel<bf16>, dim3(1), dim3(64), 0, st, (const bf16*)A, (const bf16*)Bt,
+                       (const bf16*)Brow, C_row, C_tr);
+  else
+    hipLaunchKernelGGL(selftest_mma_kernel<float>, dim3(1), dim3(64), 0, st, (const float*)A, (const float*)Bt,
+                       (const float*)Brow, C_row, C_tr);
+  VITPE_CHECK_LAUNCH();
+}
+
+extern "C" int vitpe_abi_version(void) { return 1; }

@@ -1,0 +1,210 @@
+// LayerNorm forward / backward (reference nn.LayerNorm(d), eps 1e-5: models/vit.py:113,116,210).
+// HBM-bound: one wavefront per token row, 16-byte loads, two-pass statistics in registers,
+// fp32 math.  Backward also folds in the residual-branch gradient (dx = dres + LN'(dy)) so the
+// residual add of vit.py:122,124 costs no extra pass, and reduces dgamma/dbeta through
+// per-workgroup partial rows summed in a fixed order (deterministic).
+#include "common.h"
+
+namespace vitpe {
+
+constexpr int LN_MAXC = 4;  // 16-B chunks cached per lane: D <= 64*4*8 (bf16) / 64*4*4 (fp32)
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     int M, int D, float eps) {
+  constexpr int CHN = CH<T>::n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = D / CHN;
+  const float invD = 1.0f / (float)D;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    float v[LN_MAXC][CHN];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(x + (size_t)row * D + ch * CHN), v[i]);
+#pragma unroll
+        for (int t = 0; t < CHN; ++t) s += v[i][t];
+      }
+    }
+    const float mean = wave_sum(s) * invD;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+#pragma unroll
+        for (int t = 0; t < CHN; ++t) { const float d = v[i][t] - mean; s2 += d * d; }
+      }
+    }
+    const float var = wave_sum(s2) * invD;
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        float o[CHN];
+#pragma unroll
+        for (int t = 0; t < CHN; ++t)
+          o[t] = (v[i][t] - mean) * rstd * gamma[ch * CHN + t] + beta[ch * CHN + t];
+        *reinterpret_cast<Chunk16*>(y + (size_t)row * D + ch * CHN) = f32_to_chunk<T>(o);
+      }
+    }
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+  }
+}
+
+// dx[row] = (dres ? dres[row] : 0) + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
+// partial[block][0][:] = sum_rows dy * xhat (dgamma), partial[block][1][:] = sum_rows dy (dbeta)
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                     const float* __restrict__ gamma, const T* __restrict__ dres,
+                                                     T* __restrict__ dx, float* __restrict__ partial, int M, int D) {
+  constexpr int CHN = CH<T>::n;
+  extern __shared__ __attribute__((aligned(16))) float sred[];  // [4 waves][2][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = D / CHN;
+  const float invD = 1.0f / (float)D;
+  float ag[LN_MAXC][CHN], ab[LN_MAXC][CHN], gm[LN_MAXC][CHN];
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int ch = lane + 64 * i;
+#pragma unroll
+    for (int t = 0; t < CHN; ++t) {
+      ag[i][t] = 0.f; ab[i][t] = 0.f;
+      gm[i][t] = (ch < nch) ? gamma[ch * CHN + t] : 0.f;
+    }
+  }
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float xh[LN_MAXC][CHN], g[LN_MAXC][CHN];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        float xv[CHN], dv[CHN];
+        chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(x + (size_t)row * D + ch * CHN), xv);
+        chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(dy + (size_t)row * D + ch * CHN), dv);
+#pragma unroll
+        for (int t = 0; t < CHN; ++t) {
+          xh[i][t] = (xv[t] - mean) * rstd;
+          g[i][t] = dv[t] * gm[i][t];
+          s1 += g[i][t];
+          s2 += g[i][t] * xh[i][t];
+          ag[i][t] += dv[t] * xh[i][t];
+          ab[i][t] += dv[t];
+        }
+      }
+    }
+    s1 = wave_sum(s1) * invD;
+    s2 = wave_sum(s2) * invD;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        float o[CHN];
+#pragma unroll
+        for (int t = 0; t < CHN; ++t) o[t] = rstd * (g[i][t] - s1 - xh[i][t] * s2);
+        if (dres != nullptr) {
+          float rv[CHN];
+          chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(dres + (size_t)row * D + ch * CHN), rv);
+#pragma unroll
+          for (int t = 0; t < CHN; ++t) o[t] += rv[t];
+        }
+        *reinterpret_cast<Chunk16*>(dx + (size_t)row * D + ch * CHN) = f32_to_chunk<T>(o);
+      }
+    }
+  }
+  // cross-wave reduction, fixed order
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+#pragma unroll
+      for (int t = 0; t < CHN; ++t) {
+        sred[(wave * 2 + 0) * D + ch * CHN + t] = ag[i][t];
+        sred[(wave * 2 + 1) * D + ch * CHN + t] = ab[i][t];
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * D; i += 256) {
+    const float s = sred[i] + sred[2 * D + i] + sred[4 * D + i] + sred[6 * D + i];
+    partial[(size_t)blockIdx.x * 2 * D + i] = s;
+  }
+}
+
+// dst0[i] += sum_p partial[p][i] (i < len0) ; dst1[i-len0] += ... (len0 <= i < len0+len1)
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nparts, int len0, int len1,
+                                       float* __restrict__ dst0, float* __restrict__ dst1) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int len = len0 + len1;
+  if (i >= len) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * len + i];
+  if (i < len0) dst0[i] += s; else dst1[i - len0] += s;
+}
+
+}  // namespace vitpe
+
+using namespace vitpe;
+
+extern "C" int vitpe_reduce_partials(const float* partial, int nparts, int len0, int len1, float* dst0,
+                                     float* dst1, hipStream_t stream) {
+  VITPE_REQUIRE(partial && dst0 && nparts >= 0 && len0 >= 0 && len1 >= 0 && (len1 == 0 || dst1));
+  const int len = len0 + len1;
+  if (len == 0) return 0;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((len + 255) / 256), dim3(256), 0, stream, partial, nparts,
+                     len0, len1, dst0, dst1);
+  VITPE_CHECK_LAUNCH();
+}
+
+static inline bool ln_dims_ok(int dtype, int D) {
+  const int chn = dtype == 1 ? 8 : 4;
+  return D > 0 && D % chn == 0 && D / chn <= 64 * LN_MAXC;
+}
+
+extern "C" int vitpe_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y,
+                                   float* mean, float* rstd, int M, int D, float eps, hipStream_t stream) {
+  VITPE_REQUIRE(x && gamma && beta && y && M >= 0);
+  VITPE_REQUIRE((dtype == 0 || dtype == 1) && ln_dims_ok(dtype, D));
+  if (M == 0) return 0;
+  const int blocks = min((M + 3) / 4, 2048);
+  if (dtype == 1)
+    hipLaunchKernelGGL(ln_fwd_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, (const bf16*)x, gamma, beta,
+                       (bf16*)y, mean, rstd, M, D, eps);
+  else
+    hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)x, gamma, beta,
+                       (float*)y, mean, rstd, M, D, eps);
+  VITPE_CHECK_LAUNCH();
+}
+
+extern "C" int vitpe_layernorm_bwd_blocks(int M) { return min((M + 3) / 4, 512); }
+
+// workspace: vitpe_layernorm_bwd_blocks(M) * 2 * D floats
+extern "C" int vitpe_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd,
+                                   const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta,
+                                   float* workspace, int M, int D, hipStream_t stream) {
+  VITPE_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace && M >= 0);
+  VITPE_REQUIRE((dtype == 0 || dtype == 1) && ln_dims_ok(dtype, D));
+  if (M == 0) return 0;
+  const int blocks = vitpe_layernorm_bwd_blocks(M);
+  const size_t shm = (size_t)4 * 2 * D * sizeof(float);
+  if (dtype == 1)
+    hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3(blocks), dim3(256), shm, stream, (const bf16*)dy, (const bf16*)x,
+                       mean, rstd, gamma, (const bf16*)dres, (bf16*)dx, workspace, M, D);
+  else
+    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(blocks), dim3(256), shm, stream, (const float*)dy,
+                       (const float*)x, mean, rstd, gamma, (const float*)dres, (float*)dx, workspace, M, D);
+  int e = (int)hipGetLastError();
+  if (e) return e;
+  return vitpe_reduce_partials(workspace, blocks, D, D, dgamma, dbeta, stream);
+}

@@ -1,0 +1,308 @@
+"""Tensor-level wrappers over the C ABI (include/vitpe.h).
+
+Each function validates device / dtype / shape, allocates outputs with torch (PyTorch owns all
+device memory), and enqueues the HIP kernel on torch's current stream.  No arithmetic happens
+in Python; there is no fallback path.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from ._lib import check, dtype_code, lib, ptr, require_device, stream_ptr
+
+SPLITS_TARGET_WGS = 512  # workgroups a weight-gradient launch should expose
+
+
+def _f32(t, name):
+    if t is not None and t.dtype != torch.float32:
+        raise L.VitpeError(f"{name} must be float32")
+
+
+# ---- GEMMs --------------------------------------------------------------------------------
+def gemm_nt(a, w, bias=None, epi=L.EPI_BIAS, resid=None, u=None, out=None):
+    """epi(A[M,K] W[N,K]^T) -> C[M,N]; EPI_BIAS_GELU returns (C, U)."""
+    require_device(a, w, bias, resid, u, out)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.dtype == w.dtype
+    _f32(bias, "bias")
+    c = out if out is not None else torch.empty((M, N), dtype=a.dtype, device=a.device)
+    if epi == L.EPI_BIAS_GELU and u is None:
+        u = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    check(lib().vitpe_gemm_nt(dtype_code(a.dtype), epi, ptr(a), ptr(w), ptr(c), ptr(bias), ptr(resid), ptr(u),
+                              None, None, M, N, K, 0, 0, stream_ptr()), "vitpe_gemm_nt")
+    return (c, u) if epi == L.EPI_BIAS_GELU else c
+
+
+def patch_embed_gemm(patches, w, bias, cls, ape, B, P, out=None):
+    """tokens[B,P+1,N] from unfolded patches [B*P,K] (vit.py:248-258)."""
+    require_device(patches, w, bias, cls, ape, out)
+    M, K = patches.shape
+    N = w.shape[0]
+    assert M == B * P
+    _f32(bias, "bias"), _f32(cls, "cls"), _f32(ape, "ape")
+    c = out if out is not None else torch.empty((B, P + 1, N), dtype=patches.dtype, device=patches.device)
+    check(lib().vitpe_gemm_nt(dtype_code(patches.dtype), L.EPI_PATCH, ptr(patches), ptr(w), ptr(c), ptr(bias), None,
+                              None, ptr(ape), ptr(cls), M, N, K, P, P + 1, stream_ptr()), "vitpe_gemm_nt(patch)")
+    return c
+
+
+def wgrad_splits(M, N, K):
+    tiles = ((N + 127) // 128) * ((K + 127) // 128 if (K % 128 == 0 or K > 192) else (K + 63) // 64)
+    return max(1, min(64, SPLITS_TARGET_WGS // max(tiles, 1), (M + 255) // 256))
+
+
+def gemm_tn(dy, x, dw, dbias=None, splits=None):
+    """dW[N,K] += dY[M,N]^T X[M,K]; dbias[N] += colsum(dY)."""
+    require_device(dy, x, dw, dbias)
+    M, N = dy.shape
+    K = x.shape[1]
+    assert x.shape[0] == M and dw.numel() == N * K and dy.dtype == x.dtype
+    _f32(dw, "dw"), _f32(dbias, "dbias")
+    if splits is None:
+        splits = wgrad_splits(M, N, K)
+    check(lib().vitpe_gemm_tn(dtype_code(dy.dtype), ptr(dy), ptr(x), ptr(dw), ptr(dbias), M, N, K, splits,
+                              stream_ptr()), "vitpe_gemm_tn")
+
+
+# ---- LayerNorm ------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, eps=1e-5, out=None, mean=None, rstd=None):
+    require_device(x, gamma, beta, out)
+    D = x.shape[-1]
+    M = x.numel() // D
+    _f32(gamma, "gamma"), _f32(beta, "beta")
+    y = out if out is not None else torch.empty_like(x)
+    mean = mean if mean is not None else torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = rstd if rstd is not None else torch.empty(M, dtype=torch.float32, device=x.device)
+    check(lib().vitpe_layernorm_fwd(dtype_code(x.dtype), ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd),
+                                    M, D, eps, stream_ptr()), "vitpe_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd_workspace(M, D, device):
+    return torch.empty(lib().vitpe_layernorm_bwd_blocks(M) * 2 * D, dtype=torch.float32, device=device)
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dres=None, out=None, workspace=None):
+    """dx = dres + LN'(dy); dgamma/dbeta accumulated."""
+    require_device(dy, x, mean, rstd, gamma, dgamma, dbeta, dres, out, workspace)
+    D = x.shape[-1]
+    M = x.numel() // D
+    dx = out if out is not None else torch.empty_like(x)
+    ws = workspace if workspace is not None else layernorm_bwd_workspace(M, D, x.device)
+    check(lib().vitpe_layernorm_bwd(dtype_code(x.dtype), ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres),
+                                    ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), M, D, stream_ptr()),
+          "vitpe_layernorm_bwd")
+    return dx
+
+
+# ---- fused attention ------------------------------------------------------------------------
+class PETables:
+    """Device-side positional-encoding operands of the fused attention kernels."""
+
+    def __init__(self, mode: str, grid: int, cos=None, sin=None, table=None, coeff=None, degree=0,
+                 coeff_per_head=False):
+        self.mode, self.grid = mode, grid
+        self.cos, self.sin, self.table, self.coeff = cos, sin, table, coeff
+        self.degree, self.coeff_per_head = degree, coeff_per_head
+
+    @property
+    def code(self):
+        return L.PE_CODES[self.mode]
+
+
+def fused_attention_supported(dtype, N, D, HD) -> bool:
+    return bool(lib().vitpe_fused_attention_supported(dtype_code(dtype), N, D, HD))
+
+
+def fused_attention_fwd(xn, wqkv, num_heads, pe: PETables, out=None):
+    require_device(xn, wqkv, pe.cos, pe.sin, pe.table, pe.coeff, out)
+    B, N, D = xn.shape
+    HD = D // num_heads
+    assert wqkv.shape == (3 * D, D) and wqkv.dtype == xn.dtype
+    o = out if out is not None else torch.empty_like(xn)
+    check(lib().vitpe_fused_attention_fwd(dtype_code(xn.dtype), ptr(xn), ptr(wqkv), ptr(o), B, N, D, HD, pe.code,
+                                          ptr(pe.cos), ptr(pe.sin), ptr(pe.table), ptr(pe.coeff), pe.grid,
+                                          pe.degree, int(pe.coeff_per_head), stream_ptr()),
+          "vitpe_fused_attention_fwd")
+    return o
+
+
+def fused_attention_bwd(xn, wqkv, dout, num_heads, pe: PETables, dtable=None, dcoeff=None, dfreqs=None, out=None):
+    """-> dqkv [B,N,3D]; PE-parameter gradients accumulated into dtable/dcoeff/dfreqs."""
+    require_device(xn, wqkv, dout, dtable, dcoeff, dfreqs, out)
+    B, N, D = xn.shape
+    HD = D // num_heads
+    dqkv = out if out is not None else torch.empty((B, N, 3 * D), dtype=xn.dtype, device=xn.device)
+    check(lib().vitpe_fused_attention_bwd(dtype_code(xn.dtype), ptr(xn), ptr(wqkv), ptr(dout), ptr(dqkv), B, N, D, HD,
+                                          pe.code, ptr(pe.cos), ptr(pe.sin), ptr(pe.table), ptr(pe.coeff), pe.grid,
+                                          pe.degree, int(pe.coeff_per_head), ptr(dtable), ptr(dcoeff), ptr(dfreqs),
+                                          stream_ptr()), "vitpe_fused_attention_bwd")
+    return dqkv
+
+
+# ---- patch embed ----------------------------------------------------------------------------
+def unfold(images, patch, dtype, out=None):
+    require_device(images, out)
+    _f32(images, "images")
+    B, C, S, _ = images.shape
+    g = S // patch
+    o = out if out is not None else torch.empty((B * g * g, C * patch * patch), dtype=dtype, device=images.device)
+    check(lib().vitpe_unfold(dtype_code(dtype), ptr(images), ptr(o), B, C, S, patch, stream_ptr()), "vitpe_unfold")
+    return o
+
+
+def embed_bwd(dtok, dcls, dape, out=None):
+    require_device(dtok, dcls, dape, out)
+    B, Ntok, D = dtok.shape
+    dpatch = out if out is not None else torch.empty((B * (Ntok - 1), D), dtype=dtok.dtype, device=dtok.device)
+    check(lib().vitpe_embed_bwd(dtype_code(dtok.dtype), ptr(dtok), ptr(dcls), ptr(dape), ptr(dpatch), B, Ntok, D,
+                                stream_ptr()), "vitpe_embed_bwd")
+    return dpatch
+
+
+# ---- PE tables ------------------------------------------------------------------------------
+def relative_position_index(L_, device):
+    out = torch.empty((L_, L_), dtype=torch.int64, device=device)
+    require_device(out)
+    check(lib().vitpe_relative_position_index(ptr(out), L_, stream_ptr()), "vitpe_relative_position_index")
+    return out
+
+
+def l1_distance_matrix(G, device):
+    out = torch.empty((G * G, G * G), dtype=torch.int64, device=device)
+    require_device(out)
+    check(lib().vitpe_l1_distance_matrix(ptr(out), G, stream_ptr()), "vitpe_l1_distance_matrix")
+    return out
+
+
+def rope_axial_tables(inv_freq, grid):
+    require_device(inv_freq)
+    half = inv_freq.numel() * 2
+    cos = torch.empty((grid * grid, half), dtype=torch.float32, device=inv_freq.device)
+    sin = torch.empty_like(cos)
+    check(lib().vitpe_rope_axial_tables(ptr(inv_freq), ptr(cos), ptr(sin), grid, half, stream_ptr()),
+          "vitpe_rope_axial_tables")
+    return cos, sin
+
+
+def rope_mixed_tables(freqs, grid, cos=None, sin=None):
+    require_device(freqs, cos, sin)
+    _, H, half = freqs.shape
+    if cos is None:
+        cos = torch.empty((H, grid * grid, half), dtype=torch.float32, device=freqs.device)
+        sin = torch.empty_like(cos)
+    check(lib().vitpe_rope_mixed_tables(ptr(freqs), ptr(cos), ptr(sin), H, grid, half, stream_ptr()),
+          "vitpe_rope_mixed_tables")
+    return cos, sin
+
+
+def relative_bias(table, L_):
+    require_device(table)
+    H = table.shape[0]
+    out = torch.empty((H, L_, L_), dtype=torch.float32, device=table.device)
+    check(lib().vitpe_relative_bias(ptr(table), ptr(out), H, L_, stream_ptr()), "vitpe_relative_bias")
+    return out
+
+
+def polynomial_bias(coeff, H, grid, degree, per_head):
+    require_device(coeff)
+    L_ = grid * grid + 1
+    out = torch.empty((H, L_, L_), dtype=torch.float32, device=coeff.device)
+    check(lib().vitpe_polynomial_bias(ptr(coeff), ptr(out), H, grid, degree, int(per_head), stream_ptr()),
+          "vitpe_polynomial_bias")
+    return out
+
+
+def apply_rotary(x, cos, sin):
+    """rope_utils.py:18-37 on one tensor x [B,H,P,HD] fp32."""
+    require_device(x, cos, sin)
+    _f32(x, "x")
+    B, H, P, HD = x.shape
+    per_head = cos.dim() == 3
+    y = torch.empty_like(x)
+    check(lib().vitpe_apply_rotary(ptr(x), ptr(y), ptr(cos), ptr(sin), B, H, P, HD, int(per_head), stream_ptr()),
+          "vitpe_apply_rotary")
+    return y
+
+
+# ---- head + loss ----------------------------------------------------------------------------
+def head_fwd(x, gamma, beta, wh, bh, eps=1e-5, save=False, logits=None, ws=None):
+    """logits [B,C] = Linear(LayerNorm(x[:,0])) ; ws = (xhat, yn, rstd) when save."""
+    require_device(x, gamma, beta, wh, bh, logits)
+    B, Ntok, D = x.shape
+    Cn = wh.shape[0]
+    lg = logits if logits is not None else torch.empty((B, Cn), dtype=torch.float32, device=x.device)
+    if save and ws is None:
+        ws = (torch.empty((B, D), dtype=torch.float32, device=x.device),
+              torch.empty((B, D), dtype=torch.float32, device=x.device),
+              torch.empty((B,), dtype=torch.float32, device=x.device))
+    w0, w1, w2 = ws if ws is not None else (None, None, None)
+    check(lib().vitpe_head_fwd(dtype_code(x.dtype), ptr(x), ptr(gamma), ptr(beta), ptr(wh), ptr(bh), ptr(lg), ptr(w0),
+                               ptr(w1), ptr(w2), B, Ntok, D, Cn, eps, stream_ptr()), "vitpe_head_fwd")
+    return lg, ws
+
+
+def cross_entropy(logits, labels, grad_scale=None, dlogits=None, out2=None, want_grad=True):
+    """-> (out2 = [mean loss, #correct], dlogits)."""
+    require_device(logits, labels, dlogits, out2)
+    B, Cn = logits.shape
+    assert labels.dtype == torch.int64
+    if want_grad and dlogits is None:
+        dlogits = torch.empty_like(logits)
+    o = out2 if out2 is not None else torch.empty(2, dtype=torch.float32, device=logits.device)
+    gs = (1.0 / B) if grad_scale is None else grad_scale
+    check(lib().vitpe_cross_entropy(ptr(logits), ptr(labels), ptr(dlogits), ptr(o), B, Cn, gs, stream_ptr()),
+          "vitpe_cross_entropy")
+    return o, dlogits
+
+
+def head_bwd(dlogits, wh, gamma, ws, dtype, Ntok, dwh, dbh, dgamma, dbeta, dx=None, ws_dyn=None):
+    require_device(dlogits, wh, gamma, dwh, dbh, dgamma, dbeta, dx, ws_dyn)
+    B, Cn = dlogits.shape
+    D = wh.shape[1]
+    if dx is None:
+        dx = torch.empty((B, Ntok, D), dtype=dtype, device=dlogits.device)
+    if ws_dyn is None:
+        ws_dyn = torch.empty((B, D), dtype=torch.float32, device=dlogits.device)
+    check(lib().vitpe_head_bwd(dtype_code(dtype), ptr(dlogits), ptr(wh), ptr(gamma), ptr(ws[0]), ptr(ws[1]),
+                               ptr(ws[2]), ptr(ws_dyn), ptr(dx), ptr(dwh), ptr(dbh), ptr(dgamma), ptr(dbeta), B, Ntok,
+                               D, Cn, stream_ptr()), "vitpe_head_bwd")
+    return dx
+
+
+# ---- optimizer / shadows --------------------------------------------------------------------
+def adamw_step(p, g, m, v, hp, shadow_bf16=None, zero_grad=True):
+    require_device(p, g, m, v, hp, shadow_bf16)
+    check(lib().vitpe_adamw_step(ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow_bf16), ptr(hp), p.numel(), int(zero_grad),
+                                 stream_ptr()), "vitpe_adamw_step")
+
+
+def cast(src, dtype, out=None):
+    require_device(src, out)
+    _f32(src, "src")
+    o = out if out is not None else torch.empty(src.shape, dtype=dtype, device=src.device)
+    check(lib().vitpe_cast(dtype_code(dtype), ptr(src), ptr(o), src.numel(), stream_ptr()), "vitpe_cast")
+    return o
+
+
+def transpose_cast(src, dtype, out=None):
+    """[R,C] fp32 -> [C,R] T."""
+    require_device(src, out)
+    _f32(src, "src")
+    R, C = src.shape
+    o = out if out is not None else torch.empty((C, R), dtype=dtype, device=src.device)
+    check(lib().vitpe_transpose_cast(dtype_code(dtype), ptr(src), ptr(o), R, C, stream_ptr()), "vitpe_transpose_cast")
+    return o
+
+
+def selftest_mma(a, bt, brow):
+    require_device(a, bt, brow)
+    c_row = torch.empty((16, 16), dtype=torch.float32, device=a.device)
+    c_tr = torch.empty((16, 16), dtype=torch.float32, device=a.device)
+    check(lib().vitpe_selftest_mma(dtype_code(a.dtype), ptr(a), ptr(bt), ptr(brow), ptr(c_row), ptr(c_tr),
+                                   stream_ptr()), "vitpe_selftest_mma")
+    return c_row, c_tr
