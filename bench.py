@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train images/sec of the CIFAR-10-shaped ViT (32x32, patch 4, d=192, L=6,
+H=6, --pos_encoding rope-axial theta=100, bf16) on N MI355X, synthetic data resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" = zero_grad -> forward -> mean CE -> backward -> [RCCL all-reduce] -> AdamW on one
+per-GPU batch of 512 images (weak scaling: global batch = 512*N; BASELINE.json config 4 is
+512/GPU at N=8).  Rank 0 prints ONE JSON line with `roofline` (fused attention forward kernel,
+timed live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle's train step
+on the host cores; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (REPO, os.path.join(REPO, "vit-rpe-rope_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md, chip-level parameters)
+ATTN_FWD_FLOP_PER_IMG_LAYER = 17_621_760   # qkv + QK^T + AV, N=65 d=192 H=6, 2 flop/MAC
+ATTN_FWD_BYTES_PER_IMG_LAYER = 49_920      # bf16 x in + out (weights amortised)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=512, help="per-GPU batch")
+    ap.add_argument("--pos_encoding", default="rope-axial")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    return ap.parse_args()
+
+
+def time_attention_kernel(eng, iters=100):
+    """Average launch duration of the fused attention forward kernel (layer 0 operands of the
+    engine), HIP events on the stream the kernel is launched on (torch's current stream)."""
+    from vitpe import kernels as K
+    blk, a = eng.model.blocks[0], eng.act[0]
+    call = lambda: K.fused_attention_fwd(a["xn1"], eng.Sh(blk.attn.qkv.weight), eng.H, eng.pe, out=a["a"])  # noqa: E731
+    for _ in range(10):
+        call()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    fwd_ms = e0.elapsed_time(e1) / iters
+    callb = lambda: K.fused_attention_bwd(a["xn1"], eng.Sh(blk.attn.qkv.weight), eng.dtmp, eng.H, eng.pe,  # noqa: E731
+                                          out=eng.dqkv, **eng.pe_grads)
+    for _ in range(5):
+        callb()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        callb()
+    e1.record()
+    torch.cuda.synchronize()
+    bwd_ms = e0.elapsed_time(e1) / iters
+    eng.flat_g.zero_()
+    return fwd_ms, bwd_ms
+
+
+def cpu_baseline(pos_encoding, steps=20, warmup=2, bs=128):
+    """The CPU oracle's train step (fp32 eager torch ops, same op sequence as the reference) on
+    the host cores of this box.  Baseline only; bounded to ~10-30 s."""
+    from oracle import vit_oracle as O
+    cfg = O.VitConfig(pos_encoding=pos_encoding)
+    params = O.init_params(cfg, seed=0)
+    st = O.AdamWState()
+    g = torch.Generator().manual_seed(1234)
+    images = torch.randn(bs, 3, 32, 32, generator=g)
+    labels = torch.randint(0, 10, (bs,), generator=g)
+    for _ in range(warmup):
+        O.train_step(cfg, params, st, images, labels)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        O.train_step(cfg, params, st, images, labels)
+    dt = time.perf_counter() - t0
+    return {"value": round(bs * steps / dt, 1), "unit": "images/sec", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{steps} train steps (fwd+bwd+AdamW) of bs={bs} fp32 on the CPU oracle, {pos_encoding}, "
+                      f"{dt:.1f} s, os.cpu_count()={os.cpu_count()}"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from vitpe.engine import TrainEngine
+    from vitpe.vit import VisionTransformer
+
+    torch.manual_seed(0)
+    model = VisionTransformer(img_size=32, patch_size=4, in_chans=3, num_classes=10, embed_dim=192, depth=6,
+                              num_heads=6, pos_encoding=args.pos_encoding, rope_theta=100.0).to(dev)
+    T = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    eng = TrainEngine(model, args.batch, compute_dtype=T, use_graph=not args.no_graph)
+    eng.broadcast_parameters(0)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    eng.images.copy_(torch.randn(args.batch, 3, 32, 32, generator=g, device=dev))
+    g2 = torch.Generator(device=dev).manual_seed(4321 + rank)
+    eng.labels.copy_(torch.randint(0, 10, (args.batch,), generator=g2, device=dev))
+
+    for _ in range(args.warmup):
+        eng.step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss, _ = eng.read_metrics()
+
+    fwd_ms, bwd_ms = time_attention_kernel(eng)
+    if rank == 0:
+        flops = ATTN_FWD_FLOP_PER_IMG_LAYER * args.batch
+        achieved = flops / (fwd_ms * 1e-3) / 1e12
+        line = {
+            "metric": "train images/sec, CIFAR-10 ViT d=192 L=6 H=6",
+            "value": round(world * args.batch * args.steps / elapsed, 1),
+            "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"CIFAR-10-shaped 32x32 patch4 ViT d=192 L=6 H=6, --pos_encoding {args.pos_encoding} "
+                                   f"theta=100, {args.dtype}, full train step (fwd+CE+bwd+AdamW), random-init weights",
+                       "per_gpu_batch": args.batch, "global_batch": world * args.batch,
+                       "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
+                       "final_loss_mean": round(loss / max(args.steps + args.warmup, 1), 4)},
+            "roofline": {"kernel": "attn_fwd_kernel (fused QKV-project+RoPE+QK^T+softmax+AV)", "bound": "mfma",
+                         "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "launch_ms": round(fwd_ms, 5),
+                         "algorithmic_flop_per_launch": flops,
+                         "algorithmic_bytes_per_launch": ATTN_FWD_BYTES_PER_IMG_LAYER * args.batch,
+                         "bwd_launch_ms": round(bwd_ms, 5),
+                         "bwd_achieved_tflops": round(2 * flops / (bwd_ms * 1e-3) / 1e12, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.pos_encoding)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,61 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed over RCCL ("nccl" backend on
+ROCm) / xGMI.  The reference has no distributed code at all (single process, train.py:166); the
+hot path shards naturally over images, with ONE exchange per step: the sum of the flat gradient
+bucket.  These helpers are backend-agnostic so the host logic is also covered by 2-rank gloo
+tests on CPU."""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None, device: torch.device | None = None) -> Tuple[int, int, int]:
+    """(rank, world, local_rank) from the torchrun environment; no-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl" and device is not None:
+            kw["device_id"] = device
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, world, local_rank
+
+
+def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, equal-sized shard of a global batch (global batch must divide evenly so that
+    the mean of per-rank mean gradients equals the global-batch mean gradient)."""
+    if n_items % world != 0:
+        raise ValueError(f"global batch {n_items} is not divisible by world size {world}")
+    per = n_items // world
+    return rank * per, (rank + 1) * per
+
+
+def allreduce_sum_(flat: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place SUM of the flat gradient bucket over all ranks (the only data-path collective)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return flat
+
+
+def broadcast_(flat: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat, src=src, group=group)
+    return flat
+
+
+def flat_layout(numels, align: int = 8):
+    """Offsets of parameters inside the flat buffer (each start aligned to `align` elements) and
+    the total length."""
+    offs, n = [], 0
+    for k in numels:
+        offs.append(n)
+        n += (k + align - 1) // align * align
+    return offs, n

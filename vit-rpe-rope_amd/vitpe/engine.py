@@ -1,0 +1,301 @@
+"""Train-step engine: the MI355X replacement of the reference's step loop (train.py:108-123).
+
+    zero_grad -> forward -> mean CE -> backward -> AdamW        (train.py:111-116,194-195)
+
+* every parameter lives in ONE flat fp32 buffer (master), with a flat gradient buffer and flat
+  AdamW moments next to it; the nn.Module's parameters are re-pointed at views of it, so
+  state_dict()/checkpoints keep working and the gradient all-reduce is one contiguous bucket;
+* forward and backward are explicit sequences of HIP kernels over preallocated activations
+  (no autograd graph, no allocator traffic), captured once into a HIP graph and replayed;
+* the loss / #correct stay on the device (no per-step host sync, cf. train.py:118,121);
+* data parallel: one process per GPU, gradients summed with ONE RCCL all-reduce of the flat
+  bucket per step (torch.distributed "nccl" backend == RCCL over xGMI) and averaged inside
+  the fused AdamW kernel (grad_scale = 1/world).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import _lib as L
+from . import ddp
+from . import kernels as K
+from .positional_encoding import (AbsolutePositionalEncoding, PolynomialRPE, RelativePositionalEncoding, RoPEAxial,
+                                  RoPEMixed)
+from .vit import VisionTransformer
+
+ALIGN = 8  # elements: keeps every parameter 32-B (fp32) / 16-B (bf16 shadow) aligned
+
+
+class TrainEngine:
+    def __init__(self, model: VisionTransformer, batch_size: int, compute_dtype=torch.bfloat16, lr=1e-3,
+                 weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8, process_group=None, use_graph=True):
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise L.VitpeError("TrainEngine needs the model on the HIP device (no CPU path)")
+        self.model, self.dev, self.T, self.B = model, dev, compute_dtype, batch_size
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.use_graph = use_graph
+        m = model
+        self.D, self.H, self.Lyr = m.embed_dim, m.num_heads, len(m.blocks)
+        self.p = m.patch_size
+        self.C = m.patch_embed.weight.shape[1]
+        self.P = m.num_patches
+        self.N = self.P + 1
+        self.grid = int(math.sqrt(self.P))
+        self.S = self.grid * self.p
+        self.hid = m.blocks[0].mlp.fc1.weight.shape[0]
+        self.Cn = m.num_classes
+        self.M = self.B * self.N
+        if not K.fused_attention_supported(self.T, self.N, self.D, self.D // self.H):
+            raise L.VitpeError(f"fused attention kernel does not support N={self.N}, D={self.D}, hd={self.D // self.H}")
+        self._build_flat(lr, weight_decay, betas, eps)
+        self._build_buffers()
+        self.graph_fb = self.graph_opt = None
+        self.steps_done = 0
+
+    # ---------------------------------------------------------------- parameters / shadows
+    def _build_flat(self, lr, wd, betas, eps):
+        params = list(self.model.parameters())  # de-duplicated, reference named_parameters() order
+        starts, n = ddp.flat_layout([prm.numel() for prm in params], ALIGN)
+        offs = {id(prm): o for prm, o in zip(params, starts)}
+        self.n_flat = n
+        f = dict(dtype=torch.float32, device=self.dev)
+        self.flat_p, self.flat_g = torch.zeros(n, **f), torch.zeros(n, **f)
+        self.flat_m, self.flat_v = torch.zeros(n, **f), torch.zeros(n, **f)
+        self.flat_s = torch.zeros(n, dtype=torch.bfloat16, device=self.dev) if self.T == torch.bfloat16 else None
+        self._off = offs
+        for prm in params:
+            o = offs[id(prm)]
+            view = self.flat_p[o:o + prm.numel()].view(prm.shape)
+            view.copy_(prm.data)
+            prm.data = view
+            prm.grad = self.flat_g[o:o + prm.numel()].view(prm.shape)
+        self.hp = torch.zeros(16, **f)
+        self.hp[:5] = torch.tensor([lr, betas[0], betas[1], eps, wd], **f)
+        self.hp[8] = 1.0 / self.world
+        # transposed shadows of the GEMM weights used by the data-gradient GEMMs
+        self._st: Dict[int, torch.Tensor] = {}
+        self._gemm_weights: List[nn.Parameter] = []
+        for blk in self.model.blocks:
+            for w in (blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight):
+                self._gemm_weights.append(w)
+                self._st[id(w)] = torch.empty((w.shape[1], w.shape[0]), dtype=self.T, device=self.dev)
+        self.refresh_shadows()
+
+    def Pm(self, prm):  # fp32 master view
+        return prm.data
+
+    def Gr(self, prm):  # fp32 gradient view
+        o = self._off[id(prm)]
+        return self.flat_g[o:o + prm.numel()].view(prm.shape)
+
+    def Sh(self, prm):  # compute-dtype shadow view (GEMM operand)
+        if self.T == torch.float32:
+            return prm.data
+        o = self._off[id(prm)]
+        return self.flat_s[o:o + prm.numel()].view(prm.shape)
+
+    def St(self, prm):  # transposed compute-dtype shadow
+        return self._st[id(prm)]
+
+    def refresh_shadows(self, cast_flat=True):
+        if self.T == torch.bfloat16 and cast_flat:
+            K.cast(self.flat_p, torch.bfloat16, out=self.flat_s)
+        for w in self._gemm_weights:
+            K.transpose_cast(w.data, self.T, out=self._st[id(w)])
+
+    def set_lr(self, lr: float):
+        self.hp[0] = lr
+
+    # ---------------------------------------------------------------- activations
+    def _build_buffers(self):
+        B, N, D, M, T, dev = self.B, self.N, self.D, self.M, self.T, self.dev
+        e = lambda *s, dt=T: torch.empty(*s, dtype=dt, device=dev)  # noqa: E731
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+        self.images = f(B, self.C, self.S, self.S)
+        self.labels = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.patches = e(B * self.P, self.C * self.p * self.p)
+        self.x = [e(B, N, D) for _ in range(self.Lyr + 1)]
+        self.act = []
+        for _ in range(self.Lyr):
+            self.act.append(dict(xn1=e(B, N, D), m1=f(M), r1=f(M), a=e(B, N, D), xmid=e(B, N, D), xn2=e(B, N, D),
+                                 m2=f(M), r2=f(M), h=e(M, self.hid), u=e(M, self.hid)))
+        self.logits, self.dlogits = f(B, self.Cn), f(B, self.Cn)
+        self.out2 = f(2)
+        self.metric_acc = torch.zeros(2, dtype=torch.float32, device=dev)  # [sum of mean losses, #correct]
+        self.head_ws = (f(B, D), f(B, D), f(B))
+        self.ws_dyn = f(B, D)
+        self.dxa, self.dxb, self.dtmp = e(B, N, D), e(B, N, D), e(B, N, D)
+        self.dqkv = e(B, N, 3 * D)
+        self.du = e(M, self.hid)
+        self.dpatch = e(B * self.P, D)
+        self.ln_ws = K.layernorm_bwd_workspace(M, D, dev)
+        # positional-encoding operands of the fused attention kernels
+        pe = self.model.pos_embed
+        mode = self.model.pos_encoding_type
+        self.pe = K.PETables(mode if mode != "absolute" else "none", self.grid)
+        self.pe_grads = dict(dtable=None, dcoeff=None, dfreqs=None)
+        if isinstance(pe, RelativePositionalEncoding):
+            self.pe.table = pe.relative_position_bias_table.data
+            self.pe_grads["dtable"] = self.Gr(pe.relative_position_bias_table)
+        elif isinstance(pe, PolynomialRPE):
+            self.pe.coeff, self.pe.degree = pe.coefficients.data, pe.degree
+            self.pe.coeff_per_head = not pe.shared_across_heads
+            self.pe_grads["dcoeff"] = self.Gr(pe.coefficients)
+        elif isinstance(pe, RoPEAxial):
+            self.pe.cos, self.pe.sin = K.rope_axial_tables(pe.inv_freq.contiguous(), self.grid)
+        elif isinstance(pe, RoPEMixed):
+            self.pe.cos, self.pe.sin = K.rope_mixed_tables(pe.freqs.data, self.grid)
+            self.pe_grads["dfreqs"] = self.Gr(pe.freqs)
+
+    # ---------------------------------------------------------------- forward / backward
+    def _forward(self):
+        mdl, B, N, D, M = self.model, self.B, self.N, self.D, self.M
+        K.unfold(self.images, self.p, self.T, out=self.patches)
+        ape = mdl.pos_embed.pos_embed.data[0, :self.P] if isinstance(mdl.pos_embed, AbsolutePositionalEncoding) else None
+        K.patch_embed_gemm(self.patches, self.Sh(mdl.patch_embed.weight).view(D, -1), mdl.patch_embed.bias.data,
+                           mdl.cls_token.data.view(-1), ape, B, self.P, out=self.x[0])
+        if isinstance(mdl.pos_embed, RoPEMixed):  # learnable frequencies: tables follow the parameters
+            K.rope_mixed_tables(mdl.pos_embed.freqs.data, self.grid, self.pe.cos, self.pe.sin)
+        for l, blk in enumerate(mdl.blocks):
+            a, xin = self.act[l], self.x[l]
+            K.layernorm_fwd(xin, blk.norm1.weight.data, blk.norm1.bias.data, blk.norm1.eps, out=a["xn1"],
+                            mean=a["m1"], rstd=a["r1"])
+            K.fused_attention_fwd(a["xn1"], self.Sh(blk.attn.qkv.weight), self.H, self.pe, out=a["a"])
+            K.gemm_nt(a["a"].view(M, D), self.Sh(blk.attn.proj.weight), blk.attn.proj.bias.data, epi=L.EPI_BIAS_RESID,
+                      resid=xin.view(M, D), out=a["xmid"].view(M, D))
+            K.layernorm_fwd(a["xmid"], blk.norm2.weight.data, blk.norm2.bias.data, blk.norm2.eps, out=a["xn2"],
+                            mean=a["m2"], rstd=a["r2"])
+            K.gemm_nt(a["xn2"].view(M, D), self.Sh(blk.mlp.fc1.weight), blk.mlp.fc1.bias.data, epi=L.EPI_BIAS_GELU,
+                      u=a["u"], out=a["h"])
+            K.gemm_nt(a["h"], self.Sh(blk.mlp.fc2.weight), blk.mlp.fc2.bias.data, epi=L.EPI_BIAS_RESID,
+                      resid=a["xmid"].view(M, D), out=self.x[l + 1].view(M, D))
+        K.head_fwd(self.x[-1], mdl.norm.weight.data, mdl.norm.bias.data, mdl.head.weight.data, mdl.head.bias.data,
+                   mdl.norm.eps, save=True, logits=self.logits, ws=self.head_ws)
+
+    def _loss(self):
+        K.cross_entropy(self.logits, self.labels, grad_scale=1.0 / self.B, dlogits=self.dlogits, out2=self.out2)
+        self.metric_acc.add_(self.out2)
+
+    def _backward(self):
+        mdl, B, N, D, M = self.model, self.B, self.N, self.D, self.M
+        G = self.Gr
+        K.head_bwd(self.dlogits, mdl.head.weight.data, mdl.norm.weight.data, self.head_ws, self.T, N, G(mdl.head.weight),
+                   G(mdl.head.bias), G(mdl.norm.weight), G(mdl.norm.bias), dx=self.dxa, ws_dyn=self.ws_dyn)
+        cur, other = self.dxa, self.dxb
+        for l in range(self.Lyr - 1, -1, -1):
+            blk, a = mdl.blocks[l], self.act[l]
+            # ---- MLP branch: x_out = xmid + fc2(gelu(fc1(LN2(xmid))))
+            dy = cur.view(M, D)
+            K.gemm_nt(dy, self.St(blk.mlp.fc2.weight), None, epi=L.EPI_GELU_BWD, u=a["u"], out=self.du)
+            K.gemm_tn(dy, a["h"], G(blk.mlp.fc2.weight), G(blk.mlp.fc2.bias))
+            K.gemm_nt(self.du, self.St(blk.mlp.fc1.weight), None, out=self.dtmp.view(M, D))
+            K.gemm_tn(self.du, a["xn2"].view(M, D), G(blk.mlp.fc1.weight), G(blk.mlp.fc1.bias))
+            K.layernorm_bwd(self.dtmp, a["xmid"], a["m2"], a["r2"], blk.norm2.weight.data, G(blk.norm2.weight),
+                            G(blk.norm2.bias), dres=cur, out=other, workspace=self.ln_ws)
+            cur, other = other, cur
+            # ---- attention branch: xmid = x_in + proj(attn(LN1(x_in)))
+            dy = cur.view(M, D)
+            K.gemm_nt(dy, self.St(blk.attn.proj.weight), None, out=self.dtmp.view(M, D))
+            K.gemm_tn(dy, a["a"].view(M, D), G(blk.attn.proj.weight), G(blk.attn.proj.bias))
+            K.fused_attention_bwd(a["xn1"], self.Sh(blk.attn.qkv.weight), self.dtmp, self.H, self.pe,
+                                  out=self.dqkv, **self.pe_grads)
+            K.gemm_nt(self.dqkv.view(M, 3 * D), self.St(blk.attn.qkv.weight), None, out=self.dtmp.view(M, D))
+            K.gemm_tn(self.dqkv.view(M, 3 * D), a["xn1"].view(M, D), G(blk.attn.qkv.weight), None)
+            K.layernorm_bwd(self.dtmp, self.x[l], a["m1"], a["r1"], blk.norm1.weight.data, G(blk.norm1.weight),
+                            G(blk.norm1.bias), dres=cur, out=other, workspace=self.ln_ws)
+            cur, other = other, cur
+        dape = None
+        if isinstance(mdl.pos_embed, AbsolutePositionalEncoding):
+            dape = G(mdl.pos_embed.pos_embed)[0, :self.P]
+        K.embed_bwd(cur, G(mdl.cls_token).view(-1), dape, out=self.dpatch)
+        K.gemm_tn(self.dpatch, self.patches, G(mdl.patch_embed.weight).view(D, -1), G(mdl.patch_embed.bias))
+
+    def _optimizer(self):
+        K.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.hp, shadow_bf16=self.flat_s,
+                     zero_grad=True)
+        self.refresh_shadows(cast_flat=False)
+
+    def _allreduce(self):
+        ddp.allreduce_sum_(self.flat_g, self.pg)
+
+    # ---------------------------------------------------------------- public API
+    def broadcast_parameters(self, src=0):
+        """Initial parameter broadcast from rank 0 so all replicas start identical."""
+        if self.world > 1:
+            ddp.broadcast_(self.flat_p, src, self.pg)
+            self.refresh_shadows()
+
+    def capture(self):
+        """Warm up on a side stream, then capture forward+loss+backward (and, single-GPU, the
+        optimizer) into HIP graphs.  Engine state is restored after the warm-up."""
+        snap = [t.clone() for t in (self.flat_p, self.flat_m, self.flat_v, self.hp, self.metric_acc)]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self._forward(); self._loss(); self._backward(); self._optimizer()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        for t, c in zip((self.flat_p, self.flat_m, self.flat_v, self.hp, self.metric_acc), snap):
+            t.copy_(c)
+        self.flat_g.zero_()
+        self.refresh_shadows()
+        torch.cuda.synchronize()
+        self.graph_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_fb):
+            self._forward(); self._loss(); self._backward()
+            if self.world == 1:
+                self._optimizer()
+        if self.world > 1:
+            self.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_opt):
+                self._optimizer()
+            # capture ran the optimizer kernels once: undo
+            for t, c in zip((self.flat_p, self.flat_m, self.flat_v, self.hp, self.metric_acc), snap):
+                t.copy_(c)
+            self.flat_g.zero_()
+            self.refresh_shadows()
+        torch.cuda.synchronize()
+
+    def step(self, images: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None):
+        """One training step (train.py:109-116).  `images` [B,C,S,S] fp32 / `labels` [B] int64 on the
+        device; None re-uses the resident batch.  No host synchronisation."""
+        if images is not None:
+            if images.shape[0] != self.B:
+                raise L.VitpeError(f"engine was built for batch {self.B}, got {images.shape[0]} "
+                                   "(use train_step_eager for ragged batches)")
+            self.images.copy_(images, non_blocking=True)
+            self.labels.copy_(labels, non_blocking=True)
+        if self.use_graph:
+            if self.graph_fb is None:
+                self.capture()
+            self.graph_fb.replay()
+            if self.world > 1:
+                self._allreduce()
+                self.graph_opt.replay()
+        else:
+            self._forward(); self._loss(); self._backward(); self._allreduce(); self._optimizer()
+        self.steps_done += 1
+
+    def forward_backward(self):
+        """forward + loss + backward on the resident batch without the optimizer (tests / parity)."""
+        self._forward(); self._loss(); self._backward()
+
+    def forward_only(self, images: torch.Tensor) -> torch.Tensor:
+        self.images.copy_(images)
+        self._forward()
+        return self.logits
+
+    def read_metrics(self, reset=True):
+        """(mean loss over the steps since the last read, #correct) -- the ONLY host sync."""
+        v = self.metric_acc.tolist()
+        if reset:
+            self.metric_acc.zero_()
+        return v[0], v[1]
