@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Drop-in `train.py`: every flag of the reference (train.py:27-55) is kept verbatim; the step
+loop (reference train.py:94-125) runs on the MI355X TrainEngine -- explicit HIP kernels for
+forward/backward, one captured HIP graph per step, fused AdamW, metrics accumulated on the
+device -- and shards each global minibatch data-parallel over the GPUs of the node with ONE RCCL
+all-reduce of the flat gradient bucket per step.
+
+    python train.py --dataset cifar10 --pos_encoding rope-axial --synthetic
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py \
+        --dataset cifar10 --pos_encoding rope-mixed --batch_size 4096 --synthetic
+
+Additions to the reference CLI: --synthetic (CIFAR/MNIST-shaped random batches generated on the
+device: torchvision and the dataset downloads are unavailable offline), --steps_per_epoch,
+--fp32 (exact-fp32 MFMA instead of the default bf16).  --batch_size is the GLOBAL batch.
+"""
+import argparse
+import csv
+import math
+import os
+import sys
+from datetime import datetime
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (REPO, os.path.join(REPO, "vit-rpe-rope_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def get_args(argv=None):
+    parser = argparse.ArgumentParser(description='Vision Transformer Training (MI355X)')
+    parser.add_argument('--log_dir', type=str, default='logs')
+    parser.add_argument('--ckpt_dir', type=str, default='checkpoints')
+    parser.add_argument('--dataset', type=str, default='mnist', choices=['mnist', 'cifar10'])
+    parser.add_argument('--pos_encoding', type=str, default='absolute',
+                        choices=['none', 'absolute', 'relative', 'polynomial', 'rope-axial', 'rope-mixed'])
+    parser.add_argument('--rope_theta', type=float, default=100.0)
+    parser.add_argument('--poly_degree', type=int, default=3)
+    parser.add_argument('--poly_shared_heads', action='store_true', default=True)
+    parser.add_argument('--no-poly_shared_heads', action='store_false', dest='poly_shared_heads')
+    parser.add_argument('--batch_size', type=int, default=128)
+    parser.add_argument('--epochs', type=int, default=25)
+    parser.add_argument('--lr', type=float, default=0.001)
+    parser.add_argument('--weight_decay', type=float, default=0.01)
+    parser.add_argument('--img_size', type=int, default=32)
+    parser.add_argument('--patch_size', type=int, default=4)
+    parser.add_argument('--embed_dim', type=int, default=192)
+    parser.add_argument('--depth', type=int, default=6)
+    parser.add_argument('--num_heads', type=int, default=6)
+    # additions
+    parser.add_argument('--synthetic', action='store_true', help='dataset-shaped random batches generated on the device')
+    parser.add_argument('--steps_per_epoch', type=int, default=0, help='0 = dataset size // batch_size')
+    parser.add_argument('--fp32', action='store_true', help='exact-fp32 MFMA instead of bf16')
+    return parser.parse_args(argv)
+
+
+DATASETS = {'mnist': dict(in_chans=1, num_classes=10, train=60000, test=10000),
+            'cifar10': dict(in_chans=3, num_classes=10, train=50000, test=10000)}
+
+
+class SyntheticBatches:
+    """Dataset-shaped batches drawn on the device: images ~ N(0,1) (what Normalize produces,
+    reference train.py:72,82), labels ~ U{0..9}; a fixed pool so a model can actually fit it."""
+
+    def __init__(self, n_batches, batch, in_chans, img, num_classes, device, seed):
+        g = torch.Generator(device=device).manual_seed(seed)
+        pool = max(1, min(n_batches, 8))
+        self.images = [torch.randn(batch, in_chans, img, img, generator=g, device=device) for _ in range(pool)]
+        self.labels = [torch.randint(0, num_classes, (batch,), generator=g, device=device) for _ in range(pool)]
+        self.n = n_batches
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        for i in range(self.n):
+            yield self.images[i % len(self.images)], self.labels[i % len(self.labels)]
+
+
+def get_dataset(args, info, per_rank_batch, device, rank):
+    if not args.synthetic:
+        try:
+            import torchvision  # noqa: F401
+        except ImportError:
+            raise SystemExit("torchvision / dataset download unavailable here: re-run with --synthetic")
+        raise SystemExit("real-data input pipeline is not part of this round (SURVEY 8f-3): use --synthetic")
+    n_train = args.steps_per_epoch or info['train'] // args.batch_size
+    n_test = max(1, min(n_train // 5, info['test'] // args.batch_size))
+    mk = lambda n, seed: SyntheticBatches(n, per_rank_batch, info['in_chans'], args.img_size,  # noqa: E731
+                                          info['num_classes'], device, seed)
+    return mk(n_train, 1234 + rank), mk(n_test, 4321 + rank)
+
+
+def train(engine, loader):
+    """One epoch (reference train.py:94-125) -> (avg_loss, acc%). No per-step host sync."""
+    seen = 0
+    for images, labels in loader:
+        engine.step(images, labels)
+        seen += images.shape[0]
+    loss_sum, correct = engine.read_metrics()
+    return loss_sum / max(len(loader), 1), 100. * correct / max(seen, 1)
+
+
+def test(engine, loader):
+    """Evaluation (reference train.py:127-155): forward only on the same kernels."""
+    from vitpe import kernels as K
+    loss_sum, correct, seen = 0.0, 0.0, 0
+    acc = torch.zeros(2, device=engine.dev)
+    for images, labels in loader:
+        logits = engine.forward_only(images)
+        out2, _ = K.cross_entropy(logits, labels, want_grad=False)
+        acc += out2
+        seen += images.shape[0]
+    loss_sum, correct = acc.tolist()
+    return loss_sum / max(len(loader), 1), 100. * correct / max(seen, 1)
+
+
+def main(argv=None):
+    args = get_args(argv)
+    if not torch.cuda.is_available():
+        raise SystemExit("train.py needs an MI355X: the HIP path is the only path (no CPU fallback)")
+    from vitpe import ddp
+    from vitpe.engine import TrainEngine
+    from models.vit import VisionTransformer
+
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    rank, world, _ = ddp.init_from_env(device=device)
+    lo, hi = ddp.shard_bounds(args.batch_size, rank, world)
+    per_rank = hi - lo
+    info = DATASETS[args.dataset]
+
+    log_file = None
+    if rank == 0:
+        os.makedirs(args.log_dir, exist_ok=True)
+        os.makedirs(args.ckpt_dir, exist_ok=True)
+        timestamp = datetime.now().strftime('%Y%m%d_%H%M%S')
+        log_file = f'{args.log_dir}/{args.dataset}_{args.pos_encoding}_{timestamp}.csv'
+        with open(log_file, 'w', newline='') as f:
+            csv.writer(f).writerow(['epoch', 'train_loss', 'train_acc', 'test_loss', 'test_acc', 'best_acc'])
+
+    train_loader, test_loader = get_dataset(args, info, per_rank, device, rank)
+    torch.manual_seed(0)
+    model = VisionTransformer(img_size=args.img_size, patch_size=args.patch_size, in_chans=info['in_chans'],
+                              num_classes=info['num_classes'], embed_dim=args.embed_dim, depth=args.depth,
+                              num_heads=args.num_heads, pos_encoding=args.pos_encoding, rope_theta=args.rope_theta,
+                              poly_degree=args.poly_degree, poly_shared_heads=args.poly_shared_heads).to(device)
+    engine = TrainEngine(model, per_rank, compute_dtype=torch.float32 if args.fp32 else torch.bfloat16,
+                         lr=args.lr, weight_decay=args.weight_decay)
+    engine.broadcast_parameters(0)
+
+    best_acc = 0
+    for epoch in range(args.epochs):
+        # CosineAnnealingLR(T_max=epochs), stepped per epoch (reference train.py:196,205)
+        engine.set_lr(0.5 * args.lr * (1 + math.cos(math.pi * epoch / args.epochs)))
+        train_loss, train_acc = train(engine, train_loader)
+        test_loss, test_acc = test(engine, test_loader)
+        if rank == 0:
+            print(f'\nEpoch: {epoch + 1}/{args.epochs}')
+            if test_acc > best_acc:
+                best_acc = test_acc
+                torch.save(model.state_dict(), f'{args.ckpt_dir}/{args.dataset}_{args.pos_encoding}_best.pth')
+            with open(log_file, 'a', newline='') as f:
+                csv.writer(f).writerow([epoch + 1, train_loss, train_acc, test_loss, test_acc, best_acc])
+            print(f'Train Loss: {train_loss:.4f}, Train Acc: {train_acc:.2f}%')
+            print(f'Test Loss: {test_loss:.4f}, Test Acc: {test_acc:.2f}%')
+            print(f'Best Test Acc: {best_acc:.2f}%')
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

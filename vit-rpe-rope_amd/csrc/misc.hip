@@ -213,34 +213,36 @@ __global__ __launch_bounds__(256) void head_bwd_rows_kernel(const float* __restr
     for (size_t q = D + lane; q < (size_t)Ntok * D; q += 64) drow[q] = from_f32<T>(0.f);
   }
 }
-// stage 2: column sums over the batch in a fixed order.
+// stage 2: column sums over the batch, split over batch chunks (blockIdx.y) + fp32 atomics.
 //   dWh[k][d] += sum_b dlogits[b][k]*yn[b][d] ; dbh[k] += sum_b dlogits[b][k]
 //   dgamma[d] += sum_b dyn*xhat ; dbeta[d] += sum_b dyn
 __global__ void head_bwd_params_kernel(const float* __restrict__ dlogits, const float* __restrict__ ws_yn,
                                        const float* __restrict__ ws_dyn, const float* __restrict__ ws_xhat,
-                                       float* dWh, float* dbh, float* dgamma, float* dbeta, int B, int D, int Cn) {
+                                       float* dWh, float* dbh, float* dgamma, float* dbeta, int B, int D, int Cn,
+                                       int bchunk) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
   const int nW = Cn * D;
   if (idx < nW) {
     const int k = idx / D, d = idx % D;
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dlogits[(size_t)b * Cn + k] * ws_yn[(size_t)b * D + d];
-    dWh[idx] += s;
+    for (int b = b0; b < b1; ++b) s += dlogits[(size_t)b * Cn + k] * ws_yn[(size_t)b * D + d];
+    atomicAdd(dWh + idx, s);
   } else if (idx < nW + Cn) {
     const int k = idx - nW;
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dlogits[(size_t)b * Cn + k];
-    dbh[k] += s;
+    for (int b = b0; b < b1; ++b) s += dlogits[(size_t)b * Cn + k];
+    atomicAdd(dbh + k, s);
   } else if (idx < nW + Cn + D) {
     const int d = idx - nW - Cn;
     float sg = 0.f, sb = 0.f;
-    for (int b = 0; b < B; ++b) {
+    for (int b = b0; b < b1; ++b) {
       const float dy = ws_dyn[(size_t)b * D + d];
       sg += dy * ws_xhat[(size_t)b * D + d];
       sb += dy;
     }
-    dgamma[d] += sg;
-    dbeta[d] += sb;
+    atomicAdd(dgamma + d, sg);
+    atomicAdd(dbeta + d, sb);
   }
 }
 
@@ -249,18 +251,19 @@ __global__ void head_bwd_params_kernel(const float* __restrict__ dlogits, const 
 // and repacking of the patch-token gradient rows into the GEMM layout [B*P, D]
 template <typename T>
 __global__ void embed_bwd_kernel(const T* __restrict__ dtok, float* dcls, float* dape, T* __restrict__ dpatch,
-                                 int B, int Ntok, int D) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over Ntok*D
+                                 int B, int Ntok, int D, int bchunk) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over Ntok*D ; blockIdx.y over batch chunks
   if (idx >= Ntok * D) return;
   const int n = idx / D, d = idx % D;
+  const int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
   float s = 0.f;
-  for (int b = 0; b < B; ++b) {
+  for (int b = b0; b < b1; ++b) {
     const T v = dtok[((size_t)b * Ntok + n) * D + d];
     s += to_f32(v);
     if (n >= 1) dpatch[((size_t)b * (Ntok - 1) + n - 1) * D + d] = v;
   }
-  if (n == 0) dcls[d] += s;
-  else if (dape) dape[(size_t)(n - 1) * D + d] += s;
+  if (n == 0) atomicAdd(dcls + d, s);
+  else if (dape) atomicAdd(dape + (size_t)(n - 1) * D + d, s);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -421,17 +424,19 @@ extern "C" int vitpe_head_bwd(int dtype, const float* dlogits, const float* Wh, 
                        ws_rstd, ws_dyn, (float*)dx, B, Ntok, D, Cn);
   int e = (int)hipGetLastError();
   if (e) return e;
-  hipLaunchKernelGGL(head_bwd_params_kernel, GRID1D(Cn * D + Cn + D), 0, st, dlogits, ws_yn, ws_dyn, ws_xhat, dWh,
-                     dbh, dgamma, dbeta, B, D, Cn);
+  hipLaunchKernelGGL(head_bwd_params_kernel, dim3((Cn * D + Cn + D + 255) / 256, (B + 31) / 32), dim3(256), 0, st,
+                     dlogits, ws_yn, ws_dyn, ws_xhat, dWh, dbh, dgamma, dbeta, B, D, Cn, 32);
   VITPE_CHECK_LAUNCH();
 }
 extern "C" int vitpe_embed_bwd(int dtype, const void* dtok, float* dcls, float* dape, void* dpatch, int B, int Ntok,
                                int D, hipStream_t st) {
   VITPE_REQUIRE(dtok && dcls && dpatch && B >= 0 && (dtype == 0 || dtype == 1));
   if (dtype == 1)
-    hipLaunchKernelGGL(embed_bwd_kernel<bf16>, GRID1D(Ntok * D), 0, st, (const bf16*)dtok, dcls, dape, (bf16*)dpatch, B, Ntok, D);
+    hipLaunchKernelGGL(embed_bwd_kernel<bf16>, dim3((Ntok * D + 255) / 256, (B + 15) / 16), dim3(256), 0, st,
+                       (const bf16*)dtok, dcls, dape, (bf16*)dpatch, B, Ntok, D, 16);
   else
-    hipLaunchKernelGGL(embed_bwd_kernel<float>, GRID1D(Ntok * D), 0, st, (const float*)dtok, dcls, dape, (float*)dpatch, B, Ntok, D);
+    hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3((Ntok * D + 255) / 256, (B + 15) / 16), dim3(256), 0, st,
+                       (const float*)dtok, dcls, dape, (float*)dpatch, B, Ntok, D, 16);
   VITPE_CHECK_LAUNCH();
 }
 

@@ -61,12 +61,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 }
 
 // dx[row] = (dres ? dres[row] : 0) + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
-// partial[block][0][:] = sum_rows dy * xhat (dgamma), partial[block][1][:] = sum_rows dy (dbeta)
+// dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy  (per-workgroup partial sums, then fp32 atomics)
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, const T* __restrict__ dres,
-                                                     T* __restrict__ dx, float* __restrict__ partial, int M, int D) {
+                                                     T* __restrict__ dx, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int M, int D) {
   constexpr int CHN = CH<T>::n;
   extern __shared__ __attribute__((aligned(16))) float sred[];  // [4 waves][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -136,21 +137,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
   }
   __syncthreads();
+  // 2*D atomics per workgroup onto 2*D addresses: <= 256 workgroups, a few microseconds
   for (int i = threadIdx.x; i < 2 * D; i += 256) {
     const float s = sred[i] + sred[2 * D + i] + sred[4 * D + i] + sred[6 * D + i];
-    partial[(size_t)blockIdx.x * 2 * D + i] = s;
+    atomicAdd((i < D ? dgamma + i : dbeta + (i - D)), s);
   }
 }
 
 // dst0[i] += sum_p partial[p][i] (i < len0) ; dst1[i-len0] += ... (len0 <= i < len0+len1)
 __global__ void reduce_partials_kernel(const float* __restrict__ partial, int nparts, int len0, int len1,
                                        float* __restrict__ dst0, float* __restrict__ dst1) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // block = 32 columns x 8 partial-groups; LDS tree over the groups (fixed order)
+  __shared__ float red[8][33];
   const int len = len0 + len1;
-  if (i >= len) return;
+  const int i = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * len + i];
-  if (i < len0) dst0[i] += s; else dst1[i - len0] += s;
+  if (i < len)
+    for (int p = grp; p < nparts; p += 8) s += partial[(size_t)p * len + i];
+  red[grp][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (grp == 0 && i < len) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+    if (i < len0) dst0[i] += t; else dst1[i - len0] += t;
+  }
 }
 
 }  // namespace vitpe
@@ -162,7 +173,7 @@ extern "C" int vitpe_reduce_partials(const float* partial, int nparts, int len0,
   VITPE_REQUIRE(partial && dst0 && nparts >= 0 && len0 >= 0 && len1 >= 0 && (len1 == 0 || dst1));
   const int len = len0 + len1;
   if (len == 0) return 0;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((len + 255) / 256), dim3(256), 0, stream, partial, nparts,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((len + 31) / 32), dim3(256), 0, stream, partial, nparts,
                      len0, len1, dst0, dst1);
   VITPE_CHECK_LAUNCH();
 }
@@ -187,24 +198,23 @@ extern "C" int vitpe_layernorm_fwd(int dtype, const void* x, const float* gamma,
   VITPE_CHECK_LAUNCH();
 }
 
-extern "C" int vitpe_layernorm_bwd_blocks(int M) { return min((M + 3) / 4, 512); }
+extern "C" int vitpe_layernorm_bwd_blocks(int M) { return min((M + 3) / 4, 256); }
 
 // workspace: vitpe_layernorm_bwd_blocks(M) * 2 * D floats
 extern "C" int vitpe_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd,
                                    const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta,
                                    float* workspace, int M, int D, hipStream_t stream) {
-  VITPE_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace && M >= 0);
+  VITPE_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && M >= 0);
+  (void)workspace;  // kept in the ABI; no longer needed
   VITPE_REQUIRE((dtype == 0 || dtype == 1) && ln_dims_ok(dtype, D));
   if (M == 0) return 0;
   const int blocks = vitpe_layernorm_bwd_blocks(M);
   const size_t shm = (size_t)4 * 2 * D * sizeof(float);
   if (dtype == 1)
     hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3(blocks), dim3(256), shm, stream, (const bf16*)dy, (const bf16*)x,
-                       mean, rstd, gamma, (const bf16*)dres, (bf16*)dx, workspace, M, D);
+                       mean, rstd, gamma, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, M, D);
   else
     hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(blocks), dim3(256), shm, stream, (const float*)dy,
-                       (const float*)x, mean, rstd, gamma, (const float*)dres, (float*)dx, workspace, M, D);
-  int e = (int)hipGetLastError();
-  if (e) return e;
-  return vitpe_reduce_partials(workspace, blocks, D, D, dgamma, dbeta, stream);
+                       (const float*)x, mean, rstd, gamma, (const float*)dres, (float*)dx, dgamma, dbeta, M, D);
+  VITPE_CHECK_LAUNCH();
 }
