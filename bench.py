@@ -47,7 +47,7 @@ def time_attention_kernel(eng, iters=100):
     engine), HIP events on the stream the kernel is launched on (torch's current stream)."""
     from vitpe import kernels as K
     blk, a = eng.model.blocks[0], eng.act[0]
-    call = lambda: K.fused_attention_fwd(a["xn1"], eng.Sh(blk.attn.qkv.weight), eng.H, eng.pe, out=a["a"])  # noqa: E731
+    call = lambda: K.fused_attention_fwd(a["xn1"], eng.Pk(blk.attn.qkv.weight), eng.H, eng.pe, out=a["a"])  # noqa: E731
     for _ in range(10):
         call()
     torch.cuda.synchronize()
@@ -58,7 +58,7 @@ def time_attention_kernel(eng, iters=100):
     e1.record()
     torch.cuda.synchronize()
     fwd_ms = e0.elapsed_time(e1) / iters
-    callb = lambda: K.fused_attention_bwd(a["xn1"], eng.Sh(blk.attn.qkv.weight), eng.dtmp, eng.H, eng.pe,  # noqa: E731
+    callb = lambda: K.fused_attention_bwd(a["xn1"], eng.Pk(blk.attn.qkv.weight), eng.dtmp, eng.H, eng.pe,  # noqa: E731
                                           out=eng.dqkv, **eng.pe_grads)
     for _ in range(5):
         callb()

@@ -52,7 +52,8 @@ int vitpe_abi_version(void);
  * tokens via rope_utils.py:18-37, QK^T*hd^-0.5, + RelativePositionalEncoding /
  * PolynomialRPE bias (positional_encoding.py:82-95,127-171), softmax, @V, head merge).
  *   xn    [B,N,D] T   layer-normed tokens (N = patches+1, class token first)
- *   wqkv  [3D,D]  T   attn.qkv.weight (no bias: Block passes qkv_bias=False, vit.py:110,200)
+ *   wqkv  [3D,D]  T   attn.qkv.weight (no bias: Block passes qkv_bias=False, vit.py:110,200),
+ *                     PACKED fragment-major by vitpe_pack_qkv_weights (same element count)
  *   out   [B,N,D] T   merged heads, input of attn.proj
  *   cos/sin: rope-axial [P,HD/2], rope-mixed [H,P,HD/2] contiguous fp32 (else NULL)
  *   table : relative [H,2N-1] fp32 ; coeff: polynomial [deg+1] or [H,deg+1] fp32 (else NULL)
@@ -60,6 +61,9 @@ int vitpe_abi_version(void);
  * Supported shapes: vitpe_fused_attention_supported() (HD=32, 65<=N<=80, D in {96,192});
  * anything else returns hipErrorNotSupported.                                              */
 int vitpe_fused_attention_supported(int dtype, int N, int D, int HD);
+/* fp32 master [3D,D] -> T, re-ordered so that each MFMA weight fragment of a wave is one contiguous
+ * 1 KB read: block (head, {q,k,v}, 16-row tile, 32-deep K chunk) x 64 lanes x 8 elements          */
+int vitpe_pack_qkv_weights(int dtype, const float* wqkv, void* packed, int D, int HD, vitpe_stream_t stream);
 int vitpe_fused_attention_fwd(int dtype, const void* xn, const void* wqkv, void* out, int B, int N,
                               int D, int HD, int mode, const float* cos, const float* sin,
                               const float* table, const float* coeff, int grid, int degree,
@@ -148,6 +152,12 @@ int vitpe_transpose_cast(int dtype, const float* src, void* dst, int R, int C, v
 /* ---- primitive self-test (MFMA operand maps, transposed LDS read) ------------------------- */
 int vitpe_selftest_mma(int dtype, const void* A, const void* Bt, const void* Brow, float* C_row,
                        float* C_tr, vitpe_stream_t stream);
+
+/* debug: resident workgroups/CU the runtime computes for attention kernel `which` (0 fwd rope, 1 fwd plain, 2 bwd rope) */
+int vitpe_debug_attn_occupancy(int which);
+/* debug census: bf16 D=192 plain forward; census[3*wg] = {hw_id|xcc<<32, t_start, t_end} (100 MHz ticks) */
+int vitpe_debug_attn_census(const void* xn, const void* wqkv, void* out, int B, unsigned long long* census,
+                            vitpe_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -196,7 +196,7 @@ def test_fused_attention_fwd(K, dt, mode, D, H, B):
     N, hd, G, xn, wqkv, dout, pe = attn_case(mode, D, H, B)
     ref, _, _ = oracle_attn(mode, xn, wqkv, dout, pe, H, dt)
     t = device_pe(K, mode, pe, H, G)
-    out = K.fused_attention_fwd(dev(xn, DT[dt]), dev(wqkv, DT[dt]), H, t)
+    out = K.fused_attention_fwd(dev(xn, DT[dt]), K.pack_qkv_weights(dev(wqkv), DT[dt], H), H, t)
     assert rel_err(out.float().cpu(), ref) < tol(dt)
 
 
@@ -210,7 +210,8 @@ def test_fused_attention_bwd(K, dt, mode, D, H, B):
     dtab = torch.zeros(H, 2 * N - 1, device="cuda") if mode == "relative" else None
     dcoef = torch.zeros_like(dev(pe["coeff"])) if mode.startswith("polynomial") else None
     dfr = torch.zeros(2, H, hd // 2, device="cuda") if mode == "rope-mixed" else None
-    dqkv = K.fused_attention_bwd(dev(xn, DT[dt]), dev(wqkv, DT[dt]), dev(dout, DT[dt]), H, t, dtab, dcoef, dfr)
+    dqkv = K.fused_attention_bwd(dev(xn, DT[dt]), K.pack_qkv_weights(dev(wqkv), DT[dt], H), dev(dout, DT[dt]), H, t,
+                                 dtab, dcoef, dfr)
     assert rel_err(dqkv.float().cpu(), dqkv_ref) < tol(dt)
     if mode == "relative":
         assert rel_err(dtab.cpu(), g_ref["table"]) < tol(dt)
@@ -218,6 +219,14 @@ def test_fused_attention_bwd(K, dt, mode, D, H, B):
         assert rel_err(dcoef.cpu(), g_ref["coeff"]) < tol(dt)
     if mode == "rope-mixed":
         assert rel_err(dfr.cpu(), g_ref["freqs"]) < max(tol(dt), 2e-4)
+
+
+def test_pack_qkv_weights_layout(K):
+    D, H, hd = 96, 3, 32
+    w = rnd(3 * D, D, seed=3)
+    pk = K.pack_qkv_weights(dev(w), torch.float32, H).cpu().reshape(H, 3, hd // 16, D // 32, 4, 16, 8)  # h,mat,nt,ks,g,c,e
+    ref = w.reshape(3, H, hd // 16, 16, D // 32, 4, 8).permute(1, 0, 2, 4, 5, 3, 6)  # mat,h,nt,c,ks,g,e -> h,mat,nt,ks,g,c,e
+    assert torch.equal(pk, ref)
 
 
 def test_fused_attention_unsupported_shape_is_an_error(K):

@@ -32,7 +32,8 @@ def main():
     T = torch.bfloat16
     dev = "cuda"
     r = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(T)  # noqa: E731
-    xn, wqkv = r(B, N, D), r(3 * D, D) * 0.2
+    xn = r(B, N, D)
+    wqkv = K.pack_qkv_weights(torch.randn(3 * D, D, device=dev) * 0.1, T, H)
     out, dout, dqkv = torch.empty_like(xn), r(B, N, D), torch.empty(B, N, 3 * D, device=dev, dtype=T)
     inv = 1.0 / (100.0 ** (torch.arange(0, 8, dtype=torch.float) / 8))
     pe = K.PETables("rope-axial", 8)

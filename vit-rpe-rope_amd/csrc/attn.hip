@@ -31,7 +31,7 @@ namespace vitpe {
 
 struct AttnArgs {
   const void* xn;      // [B,N,D] T, layer-normed tokens
-  const void* wqkv;    // [3D,D] T
+  const void* wqkv;    // attn.qkv.weight [3D,D] packed fragment-major by vitpe_pack_qkv_weights (T)
   void* out;           // fwd: [B,N,D] T merged heads ; bwd: d_qkv [B,N,3D] T
   const void* dout;    // bwd: [B,N,D] T gradient of the merged-head output
   const float* cos;    // rope: axial [P,HD/2], mixed [H,P,HD/2] (contiguous)
@@ -44,7 +44,24 @@ struct AttnArgs {
   int B, N;
   int mode, grid, degree, coeff_per_head;
   float scale;
+  unsigned long long* census;  // debug: per workgroup {hw_id | xcc_id<<32, t_start, t_end} or null
 };
+
+constexpr int CENSUS_SLOTS = 32;
+// debug only (a.census == nullptr in every product launch): lane 0 of every wave stamps the
+// shader clock at phase boundaries: census[(wg*16 + wave)*CENSUS_SLOTS + slot]
+VITPE_DEV void census_stamp(const AttnArgs& a, int slot) {
+  if (a.census != nullptr && (threadIdx.x & 63) == 0) {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    unsigned long long* p = a.census + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * CENSUS_SLOTS;
+    if (slot == 0) {
+      unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, 32 bits
+      unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // HW_REG_XCC_ID
+      p[CENSUS_SLOTS - 1] = ((unsigned long long)xcc << 32) | hw;
+    }
+    p[slot] = t;
+  }
+}
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
@@ -110,29 +127,37 @@ VITPE_DEV float pe_bias2(const AttnArgs& a, const float* s_tab, const float* s_c
 // ---- stage the image's tokens, PE tables (x log2 e); zero the tails ------------------------
 template <typename T, typename C, int KM>
 VITPE_DEV void stage_tokens(const AttnArgs& a, int b, T* xs, T* hbuf, int hbuf_elems, float* s_tab, float* s_coef,
-                            int nthreads) {
+                            int tid, int nthreads, bool stage_tables) {
   constexpr int CHN = CH<T>::n;
   constexpr int DCH = C::LDX / CHN;  // chunks per LDS row incl. pad
   constexpr int D = C::DD;
   const int N = C::ntok(a);
-  const int tid = threadIdx.x;
   const T* xg = reinterpret_cast<const T*>(a.xn) + (size_t)b * N * D;
   const Chunk16 zero = {0u, 0u, 0u, 0u};
-  for (int q = tid; q < C::NP * DCH; q += nthreads) {
-    const int row = q / DCH, cc = q % DCH;
-    Chunk16 v = zero;
-    if (row < N && cc * CHN < D) v = *reinterpret_cast<const Chunk16*>(xg + (size_t)row * D + cc * CHN);
-    *reinterpret_cast<Chunk16*>(xs + row * C::LDX + cc * CHN) = v;
+  // all global loads of this thread first, then the LDS stores: one exposed latency, not one per chunk
+  constexpr int TOTAL = C::NP * DCH;
+  constexpr int ITERS = (TOTAL + 383) / 384;
+  Chunk16 v[ITERS];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int q = tid + it * nthreads, row = q / DCH, cc = q % DCH;
+    v[it] = zero;
+    if (q < TOTAL && row < N && cc * CHN < D) v[it] = *reinterpret_cast<const Chunk16*>(xg + (size_t)row * D + cc * CHN);
   }
-  // zero every head tile once: rows >= NP are never written again and must read as 0
+  // zero what must read as zero and is never written again (whole buffer when zero_all, else the caller's tails)
   for (int q = tid; q < hbuf_elems / CHN; q += nthreads) *reinterpret_cast<Chunk16*>(hbuf + q * CHN) = zero;
-  if (KM == KM_RELATIVE) {
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int q = tid + it * nthreads, row = q / DCH, cc = q % DCH;
+    if (q < TOTAL) *reinterpret_cast<Chunk16*>(xs + row * C::LDX + cc * CHN) = v[it];
+  }
+  if (KM == KM_RELATIVE && stage_tables) {
     for (int q = tid; q < C::H * C::TABLD; q += nthreads) {
       const int h = q / C::TABLD, i = q % C::TABLD;
       s_tab[q] = (i < 2 * N - 1) ? a.table[h * (2 * N - 1) + i] * LOG2E : 0.f;
     }
   }
-  if (KM == KM_POLY) {
+  if (KM == KM_POLY && stage_tables) {
     for (int q = tid; q < C::H * (C::MAXDEG + 1); q += nthreads) {
       const int h = q / (C::MAXDEG + 1), k = q % (C::MAXDEG + 1);
       float v = 0.f;
@@ -150,15 +175,16 @@ VITPE_DEV void stage_tokens(const AttnArgs& a, int b, T* xs, T* hbuf, int hbuf_e
 template <typename T, typename C>
 struct WFrags { Frag<T> f[C::NT][C::KS]; };
 
+// Packed layout (vitpe_pack_qkv_weights): block (h, mat, nt, ks) = 64 lanes x 8 elements, so one
+// fragment load of a wave is ONE contiguous 1 KB (bf16) read -- fragment-shaped loads from the
+// row-major matrix touch 16 half cache lines each and are address-unit bound (measured).
 template <typename T, typename C>
 VITPE_DEV void load_w(const AttnArgs& a, WFrags<T, C>& w, int h, int mat, int lane) {
-  constexpr int D = C::DD, HD = C::HDD;
-  const int c = lane & 15, g = lane >> 4;
-  const T* W = reinterpret_cast<const T*>(a.wqkv) + (size_t)(mat * D + h * HD) * D + (size_t)c * D + 8 * g;
+  const T* W = reinterpret_cast<const T*>(a.wqkv) + ((size_t)(h * 3 + mat) * C::NT * C::KS * 64 + lane) * 8;
 #pragma unroll
   for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) w.f[nt][ks] = ld_frag(W + (size_t)(16 * nt) * D + 32 * ks);
+    for (int ks = 0; ks < C::KS; ++ks) w.f[nt][ks] = ld_frag(W + (size_t)(nt * C::KS + ks) * 64 * 8);
 }
 
 template <typename T, typename C, int KM>
@@ -257,41 +283,60 @@ VITPE_DEV float logits_T(const AttnArgs& a, const T* kh, const Frag<T>* bq, cons
 // =========================================================================================
 // Forward
 // =========================================================================================
-template <typename T, int HD, int D, int MT, int HPP, int KM, int NTOK>
-__global__ __launch_bounds__(384, (sizeof(T) == 2 ? 3 : 2)) void attn_fwd_kernel(AttnArgs a) {
+// IPW images per workgroup (6 waves each).  Two 6-wave workgroups with > 64 KB of LDS are never
+// co-resident on a CU (measured with a residency census), so the bf16 build puts two images in ONE
+// 12-wave workgroup: each image's waves run independently between the shared barriers and fill the
+// other image's stalls.
+template <typename T, int HD, int D, int MT, int HPP, int KM, int NTOK, int IPW>
+__global__ __launch_bounds__(384 * IPW) void attn_fwd_kernel(AttnArgs a) {
   using C = AttnCfg<T, HD, D, MT, HPP, NTOK>;
-  __shared__ __attribute__((aligned(16))) T xs[C::NP * C::LDX];
   // q,k: [hh][NP][LDH] (row reads only) ; v: [hh][VR][LDH] (column reads run into the zero tail)
   constexpr int HB_ELEMS = HPP * (2 * C::QSZ + C::HSZ);
-  __shared__ __attribute__((aligned(16))) T hb[HB_ELEMS];
+  __shared__ __attribute__((aligned(16))) T xs_all[IPW * C::NP * C::LDX];
+  __shared__ __attribute__((aligned(16))) T hb_all[IPW * HB_ELEMS];
   __shared__ __attribute__((aligned(16))) float s_tab[KM == KM_RELATIVE ? C::H * C::TABLD : 4];
   __shared__ float s_coef[C::H * (C::MAXDEG + 1)];
+
+  const int N = C::ntok(a);
+  const int lane = threadIdx.x & 63;
+  const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int img = wave_all / 6, wave = wave_all % 6;
+  const int b = blockIdx.x * IPW + img;
+  const bool live = b < a.B;                       // odd batch: the second image slot idles (but keeps the barriers)
+  const int c = lane & 15, g = lane >> 4;
+  T* const xs = xs_all + img * C::NP * C::LDX;
+  T* const hb = hb_all + img * HB_ELEMS;
   T* const qb = hb;
   T* const kb = hb + HPP * C::QSZ;
   T* const vb = hb + 2 * HPP * C::QSZ;
 
-  const int N = C::ntok(a);
-  const int b = blockIdx.x;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int c = lane & 15, g = lane >> 4;
-
-  T* outp = reinterpret_cast<T*>(a.out) + (size_t)b * N * D;
+  T* outp = reinterpret_cast<T*>(a.out) + (size_t)(live ? b : 0) * N * D;
+  census_stamp(a, 0);
   WFrags<T, C> wf;
   {
     const int hh = wave / 3, mat = wave % 3;
     if (hh < HPP && hh < C::H) load_w<T, C>(a, wf, hh, mat, lane);  // pass 0 weights fly under the token staging
   }
-  stage_tokens<T, C, KM>(a, b, xs, hb, HB_ELEMS, s_tab, s_coef, 384);
+  // only the V tails (rows NP..VR-1) must read as zero: every other row is rewritten by each projection
+  static_assert((C::VR - C::NP) * C::LDH % CH<T>::n == 0, "tail");
+#pragma unroll
+  for (int hh = 0; hh < HPP; ++hh)
+    for (int q = (threadIdx.x % 384); q < (C::VR - C::NP) * C::LDH / CH<T>::n; q += 384)
+      *reinterpret_cast<Chunk16*>(vb + hh * C::HSZ + C::NP * C::LDH + q * CH<T>::n) = (Chunk16){0u, 0u, 0u, 0u};
+  stage_tokens<T, C, KM>(a, live ? b : 0, xs, hb, 0, s_tab, s_coef, (threadIdx.x % 384), 384, img == 0);
+  census_stamp(a, 1);
   __syncthreads();
+  census_stamp(a, 2);
   for (int h0 = 0; h0 < C::H; h0 += HPP) {
     {
       const int hh = wave / 3, mat = wave % 3, h = h0 + hh;
       T* dst = (mat == 0) ? qb + hh * C::QSZ : (mat == 1) ? kb + hh * C::QSZ : vb + hh * C::HSZ;
       if (hh < HPP && h < C::H) project_head<T, C, KM>(a, wf, xs, dst, h, mat, lane);
+      census_stamp(a, 3 + 4 * (h0 / HPP));
       if (hh < HPP && h + HPP < C::H) load_w<T, C>(a, wf, h + HPP, mat, lane);  // next pass, under the core
     }
     __syncthreads();
+    census_stamp(a, 4 + 4 * (h0 / HPP));
     for (int job = wave; job < HPP * MT; job += 6) {
       const int hh = job / MT, it = job % MT, h = h0 + hh;
       if (h >= C::H) continue;
@@ -326,15 +371,18 @@ __global__ __launch_bounds__(384, (sizeof(T) == 2 ? 3 : 2)) void attn_fwd_kernel
       }
       const float inv = __builtin_amdgcn_rcpf(l);
       const int i = 16 * it + c;
-      if (it < MT - 1 || i < N) {
+      if (live && (it < MT - 1 || i < N)) {
 #pragma unroll
         for (int dt = 0; dt < C::NT; ++dt)
           st4(outp + (size_t)i * D + h * HD + 16 * dt + 4 * g, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv,
               o[dt][3] * inv);
       }
     }
+    census_stamp(a, 5 + 4 * (h0 / HPP));
     __syncthreads();
+    census_stamp(a, 6 + 4 * (h0 / HPP));
   }
+  census_stamp(a, 30);
 }
 
 // =========================================================================================
@@ -363,7 +411,7 @@ __global__ __launch_bounds__(384) void attn_bwd_kernel(AttnArgs a) {
     const int hh = wave / 3, mat = wave % 3;
     if (hh < HPP && hh < C::H) load_w<T, C>(a, wf, hh, mat, lane);
   }
-  stage_tokens<T, C, KM>(a, b, xs, hb, 4 * HPP * C::HSZ, s_tab, s_coef, 384);
+  stage_tokens<T, C, KM>(a, b, xs, hb, 4 * HPP * C::HSZ, s_tab, s_coef, threadIdx.x, 384, true);
   if (KM == KM_RELATIVE)
     for (int q = threadIdx.x; q < C::H * C::TABLD; q += 384) s_dtab[q] = 0.f;
   for (int q = threadIdx.x; q < C::H * (C::MAXDEG + 1); q += 384) s_dcoef[q] = 0.f;
@@ -644,16 +692,47 @@ __global__ __launch_bounds__(384) void attn_bwd_kernel(AttnArgs a) {
   }
 }
 
+// dst block (h, mat, nt, ks), lane l = 16g + c, element e  <-  W[mat*D + h*HD + 16nt + c][32ks + 8g + e]
+template <typename T>
+__global__ void pack_qkv_kernel(const float* __restrict__ w, T* __restrict__ dst, int D, int HD) {
+  const int NT = HD / 16, KS = D / 32, H = D / HD;
+  const long long total = (long long)3 * D * D;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int e = (int)(idx & 7), l = (int)((idx >> 3) & 63);
+    long long blk = idx >> 9;
+    const int ks = (int)(blk % KS); blk /= KS;
+    const int nt = (int)(blk % NT); blk /= NT;
+    const int mat = (int)(blk % 3);
+    const int h = (int)(blk / 3);
+    if (h >= H) continue;
+    const int c = l & 15, g = l >> 4;
+    dst[idx] = from_f32<T>(w[(size_t)(mat * D + h * HD + 16 * nt + c) * D + 32 * ks + 8 * g + e]);
+  }
+}
+
 }  // namespace vitpe
 
 using namespace vitpe;
 
+extern "C" int vitpe_pack_qkv_weights(int dtype, const float* wqkv, void* packed, int D, int HD, hipStream_t stream) {
+  VITPE_REQUIRE(wqkv && packed && D > 0 && HD > 0 && D % HD == 0 && HD % 16 == 0 && D % 32 == 0);
+  VITPE_REQUIRE(dtype == 0 || dtype == 1);
+  const long long total = (long long)3 * D * D;
+  const unsigned blocks = (unsigned)min((total + 255) / 256, (long long)2048);
+  if (dtype == 1) hipLaunchKernelGGL(pack_qkv_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, wqkv, (bf16*)packed, D, HD);
+  else hipLaunchKernelGGL(pack_qkv_kernel<float>, dim3(blocks), dim3(256), 0, stream, wqkv, (float*)packed, D, HD);
+  VITPE_CHECK_LAUNCH();
+}
+
 template <typename T, int HD, int D, int MT, int HPP, int KM, int NTOK>
 static int launch_attn3(bool bwd, const AttnArgs& a, hipStream_t s) {
+  constexpr int IPW = (sizeof(T) == 2) ? 2 : 1;  // bf16 forward: two images per 12-wave workgroup
   if (bwd)
     hipLaunchKernelGGL((attn_bwd_kernel<T, HD, D, MT, HPP, KM, NTOK>), dim3(a.B), dim3(384), 0, s, a);
   else
-    hipLaunchKernelGGL((attn_fwd_kernel<T, HD, D, MT, HPP, KM, NTOK>), dim3(a.B), dim3(384), 0, s, a);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, HD, D, MT, HPP, KM, NTOK, IPW>), dim3((a.B + IPW - 1) / IPW), dim3(384 * IPW), 0,
+                       s, a);
   VITPE_CHECK_LAUNCH();
 }
 
@@ -734,4 +813,25 @@ extern "C" int vitpe_fused_attention_bwd(int dtype, const void* xn, const void* 
   a.B = B; a.N = N; a.mode = mode; a.grid = grid; a.degree = degree; a.coeff_per_head = coeff_per_head;
   a.scale = 1.0f / sqrtf((float)HD);
   return dispatch_attn(true, dtype, D, HD, a, stream);
+}
+
+// debug: what the runtime believes about residency of the main attention instantiations
+extern "C" int vitpe_debug_attn_census(const void* xn, const void* wqkv, void* out, int B, unsigned long long* census,
+                                       hipStream_t stream) {
+  AttnArgs a{};
+  a.xn = xn; a.wqkv = wqkv; a.out = out; a.B = B; a.N = 65; a.mode = PE_NONE; a.grid = 8; a.scale = 0.17677669f;
+  a.census = census;
+  return launch_attn3<bf16, 32, 192, 5, 2, KM_PLAIN, 65>(false, a, stream);
+}
+
+extern "C" int vitpe_debug_attn_occupancy(int which) {
+  int n = -1;
+  hipError_t e;
+  if (which == 0)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<bf16, 32, 192, 5, 2, KM_ROPE, 65, 2>, 768, 0);
+  else if (which == 1)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<bf16, 32, 192, 5, 2, KM_PLAIN, 65, 2>, 768, 0);
+  else
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_kernel<bf16, 32, 192, 5, 2, KM_ROPE, 65>, 384, 0);
+  return e == hipSuccess ? n : -(int)e;
 }

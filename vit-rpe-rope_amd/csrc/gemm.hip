@@ -43,8 +43,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int M = a.M, N = a.N, K = a.K;
+  // 1-D grid, XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each
+  // XCD a contiguous run of tiles, with the N-tiles of one row panel adjacent -> the A panel is
+  // fetched into ONE L2 once and the (small) weight matrix stays resident in every L2.
+  const int ntn = (N + BN - 1) / BN, ntm = (M + BM - 1) / BM, total = ntn * ntm;
+  int t;
+  {
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int q = total >> 3, r = total & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int m0 = (t / ntn) * BM, n0 = (t % ntn) * BN;
   const T* __restrict__ A = reinterpret_cast<const T*>(a.A);
   const T* __restrict__ W = reinterpret_cast<const T*>(a.W);
 
@@ -309,7 +319,7 @@ using namespace vitpe;
 
 template <typename T>
 static int launch_gemm_nt(int epi, const GemmNTArgs& a, hipStream_t s) {
-  dim3 grid((a.M + 127) / 128, (a.N + 63) / 64), block(256);
+  dim3 grid(((a.M + 127) / 128) * ((a.N + 63) / 64)), block(256);
   switch (epi) {
     case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS>), grid, block, 0, s, a); break;
     case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS_GELU>), grid, block, 0, s, a); break;

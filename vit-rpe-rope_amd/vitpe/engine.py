@@ -81,11 +81,13 @@ class TrainEngine:
         self.hp[8] = 1.0 / self.world
         # transposed shadows of the GEMM weights used by the data-gradient GEMMs
         self._st: Dict[int, torch.Tensor] = {}
+        self._pk: Dict[int, torch.Tensor] = {}   # fragment-major packed qkv weights (attention kernels)
         self._gemm_weights: List[nn.Parameter] = []
         for blk in self.model.blocks:
             for w in (blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight):
                 self._gemm_weights.append(w)
                 self._st[id(w)] = torch.empty((w.shape[1], w.shape[0]), dtype=self.T, device=self.dev)
+            self._pk[id(blk.attn.qkv.weight)] = torch.empty(blk.attn.qkv.weight.shape, dtype=self.T, device=self.dev)
         self.refresh_shadows()
 
     def Pm(self, prm):  # fp32 master view
@@ -104,11 +106,16 @@ class TrainEngine:
     def St(self, prm):  # transposed compute-dtype shadow
         return self._st[id(prm)]
 
+    def Pk(self, prm):  # packed qkv weights
+        return self._pk[id(prm)]
+
     def refresh_shadows(self, cast_flat=True):
         if self.T == torch.bfloat16 and cast_flat:
             K.cast(self.flat_p, torch.bfloat16, out=self.flat_s)
         for w in self._gemm_weights:
             K.transpose_cast(w.data, self.T, out=self._st[id(w)])
+        for blk in self.model.blocks:
+            K.pack_qkv_weights(blk.attn.qkv.weight.data, self.T, self.H, out=self._pk[id(blk.attn.qkv.weight)])
 
     def set_lr(self, lr: float):
         self.hp[0] = lr
@@ -167,7 +174,7 @@ class TrainEngine:
             a, xin = self.act[l], self.x[l]
             K.layernorm_fwd(xin, blk.norm1.weight.data, blk.norm1.bias.data, blk.norm1.eps, out=a["xn1"],
                             mean=a["m1"], rstd=a["r1"])
-            K.fused_attention_fwd(a["xn1"], self.Sh(blk.attn.qkv.weight), self.H, self.pe, out=a["a"])
+            K.fused_attention_fwd(a["xn1"], self.Pk(blk.attn.qkv.weight), self.H, self.pe, out=a["a"])
             K.gemm_nt(a["a"].view(M, D), self.Sh(blk.attn.proj.weight), blk.attn.proj.bias.data, epi=L.EPI_BIAS_RESID,
                       resid=xin.view(M, D), out=a["xmid"].view(M, D))
             K.layernorm_fwd(a["xmid"], blk.norm2.weight.data, blk.norm2.bias.data, blk.norm2.eps, out=a["xn2"],
@@ -204,7 +211,7 @@ class TrainEngine:
             dy = cur.view(M, D)
             K.gemm_nt(dy, self.St(blk.attn.proj.weight), None, out=self.dtmp.view(M, D))
             K.gemm_tn(dy, a["a"].view(M, D), G(blk.attn.proj.weight), G(blk.attn.proj.bias))
-            K.fused_attention_bwd(a["xn1"], self.Sh(blk.attn.qkv.weight), self.dtmp, self.H, self.pe,
+            K.fused_attention_bwd(a["xn1"], self.Pk(blk.attn.qkv.weight), self.dtmp, self.H, self.pe,
                                   out=self.dqkv, **self.pe_grads)
             K.gemm_nt(self.dqkv.view(M, 3 * D), self.St(blk.attn.qkv.weight), None, out=self.dtmp.view(M, D))
             K.gemm_tn(self.dqkv.view(M, 3 * D), a["xn1"].view(M, D), G(blk.attn.qkv.weight), None)

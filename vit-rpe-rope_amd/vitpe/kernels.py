@@ -118,11 +118,23 @@ def fused_attention_supported(dtype, N, D, HD) -> bool:
     return bool(lib().vitpe_fused_attention_supported(dtype_code(dtype), N, D, HD))
 
 
+def pack_qkv_weights(wqkv_f32, dtype, num_heads, out=None):
+    """fp32 master [3D,D] -> fragment-major packed T copy consumed by the fused attention kernels."""
+    require_device(wqkv_f32, out)
+    _f32(wqkv_f32, "wqkv")
+    D = wqkv_f32.shape[1]
+    o = out if out is not None else torch.empty((3 * D, D), dtype=dtype, device=wqkv_f32.device)
+    check(lib().vitpe_pack_qkv_weights(dtype_code(dtype), ptr(wqkv_f32), ptr(o), D, D // num_heads, stream_ptr()),
+          "vitpe_pack_qkv_weights")
+    return o
+
+
 def fused_attention_fwd(xn, wqkv, num_heads, pe: PETables, out=None):
+    """wqkv: PACKED weights (pack_qkv_weights)."""
     require_device(xn, wqkv, pe.cos, pe.sin, pe.table, pe.coeff, out)
     B, N, D = xn.shape
     HD = D // num_heads
-    assert wqkv.shape == (3 * D, D) and wqkv.dtype == xn.dtype
+    assert wqkv.numel() == 3 * D * D and wqkv.dtype == xn.dtype
     o = out if out is not None else torch.empty_like(xn)
     check(lib().vitpe_fused_attention_fwd(dtype_code(xn.dtype), ptr(xn), ptr(wqkv), ptr(o), B, N, D, HD, pe.code,
                                           ptr(pe.cos), ptr(pe.sin), ptr(pe.table), ptr(pe.coeff), pe.grid,

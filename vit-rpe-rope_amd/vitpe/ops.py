@@ -81,7 +81,7 @@ def attention(xn: Tensor, wqkv: Tensor, wproj: Tensor, bproj: Tensor, resid: Opt
     dt = xn.dtype
     B, N, D = xn.shape
     t = _pe_tables(mode, grid, pe_param, inv_freq, degree, per_head)
-    a = K.fused_attention_fwd(xn.contiguous(), _shadow(wqkv, dt), num_heads, t)
+    a = K.fused_attention_fwd(xn.contiguous(), K.pack_qkv_weights(wqkv.contiguous(), dt, num_heads), num_heads, t)
     if resid is None:
         y = K.gemm_nt(a.view(B * N, D), _shadow(wproj, dt), bproj, epi=L.EPI_BIAS)
     else:
@@ -117,7 +117,8 @@ def _attn_backward(ctx, dy, _da):
     t = _pe_tables(mode, grid, pe_param, inv_freq, degree, per_head)
     dpe = torch.zeros_like(pe_param) if pe_param is not None else None
     name = MODES[mode]
-    dqkv = K.fused_attention_bwd(xn.contiguous(), _shadow(wqkv, dt), da.view(B, N, D), num_heads, t,
+    dqkv = K.fused_attention_bwd(xn.contiguous(), K.pack_qkv_weights(wqkv.contiguous(), dt, num_heads),
+                                 da.view(B, N, D), num_heads, t,
                                  dtable=dpe if name == "relative" else None,
                                  dcoeff=dpe if name == "polynomial" else None,
                                  dfreqs=dpe if name == "rope-mixed" else None)
