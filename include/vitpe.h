@@ -88,6 +88,14 @@ int vitpe_fused_attention_bwd(int dtype, const void* xn, const void* wqkv, const
 int vitpe_gemm_nt(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
                   const void* R, void* U, const float* ape, const float* cls, int M, int N, int K,
                   int P, int Ntok, vitpe_stream_t stream);
+/* vitpe_linear: same contract as vitpe_gemm_nt (minus EPI_PATCH) on the second-generation panel
+ * kernel (144x192 tiles = full output rows for N = 192; used whenever N % 192 == 0, otherwise it
+ * forwards to vitpe_gemm_nt).  mean_out/rstd_out (both or neither; N == 192 only) receive the
+ * LayerNorm statistics of the OUTPUT rows (eps as in nn.LayerNorm), so the following LayerNorm
+ * (vit.py:113,116) needs no pass of its own.                                                 */
+int vitpe_linear(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
+                 const void* R, void* U, float* mean_out, float* rstd_out, float eps, int M, int N,
+                 int K, vitpe_stream_t stream);
 /* vitpe_gemm_tn: dW[N,K] += dY[M,N]^T X[M,K] ; dbias[N] += colsum(dY) (NULL to skip).  fp32
  * outputs, accumulated with atomics over `splits` token slices.                             */
 int vitpe_gemm_tn(int dtype, const void* dY, const void* X, float* dW, float* dbias, int M, int N,

@@ -93,6 +93,35 @@ def test_gemm_nt_gelu_resid_gelubwd(K, dt):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K_", [(397, 192, 192), (1300, 768, 192), (650, 192, 768), (260, 192, 576), (33, 384, 96), (130, 192, 96)])
+def test_linear_panel_kernel_all_epilogues(K, dt, M, N, K_):
+    a, w, b = rnd(M, K_, seed=1), rnd(N, K_, seed=2, scale=0.2), rnd(N, seed=3)
+    ref = q(a, dt) @ q(w, dt).t() + b
+    A, W = dev(a, DT[dt]), dev(w, DT[dt])
+    out = K.linear(A, W, dev(b), epi=0)
+    assert rel_err(out.float().cpu(), ref) < tol(dt)
+    assert rel_err(K.linear(A, W, None, epi=0).float().cpu(), ref - b) < tol(dt)
+    r = rnd(M, N, seed=4)
+    out = K.linear(A, W, dev(b), epi=2, resid=dev(r, DT[dt]))
+    assert rel_err(out.float().cpu(), ref + q(r, dt)) < tol(dt)
+    h, u = K.linear(A, W, dev(b), epi=1)
+    assert rel_err(u.float().cpu(), ref) < tol(dt)
+    assert rel_err(h.float().cpu(), torch.nn.functional.gelu(ref)) < tol(dt)
+    uu = rnd(M, N, seed=5, scale=3.0)
+    ug = q(uu, dt).requires_grad_(True)
+    torch.nn.functional.gelu(ug).sum().backward()
+    out = K.linear(A, W, None, epi=4, u=dev(uu, DT[dt]))
+    assert rel_err(out.float().cpu(), (ref - b) * ug.grad) < tol(dt)
+    if N == 192:  # fused LayerNorm statistics of the output rows
+        mean = torch.empty(M, device="cuda")
+        rstd = torch.empty(M, device="cuda")
+        out = K.linear(A, W, dev(b), epi=2, resid=dev(r, DT[dt]), stats=(mean, rstd))
+        o = out.float().cpu()
+        assert rel_err(mean.cpu(), o.mean(-1)) < 1e-4
+        assert rel_err(rstd.cpu(), 1.0 / torch.sqrt(o.var(-1, unbiased=False) + 1e-5)) < 1e-4
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("M,N,K_,splits", [(195, 96, 96, 1), (650, 576, 192, 4), (333, 192, 768, 3), (260, 192, 48, 2), (200, 96, 384, 5)])
 def test_gemm_tn_wgrad(K, dt, M, N, K_, splits):
     dy, x = rnd(M, N, seed=1), rnd(M, K_, seed=2)

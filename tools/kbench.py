@@ -70,6 +70,14 @@ def main():
     wqt = r(D, 3 * D) * 0.1
     dq2 = dqkv.view(M, 3 * D)
     rec("gemm_nt dgrad qkv [M,192]x576", timeit(lambda: K.gemm_nt(dq2, wqt, None, out=y)), 2 * M * D * 3 * D, (M * 3 * D + M * D) * 2)
+    rec("linear  fc1+gelu  [M,768]x192", timeit(lambda: K.linear(x2, w1, b1, epi=L.EPI_BIAS_GELU, u=u, out=h)), fl1, (M * D + 2 * M * hid) * 2)
+    rec("linear  fc2+resid [M,192]x768", timeit(lambda: K.linear(h, w2, b2, epi=L.EPI_BIAS_RESID, resid=x2, out=y)), fl1, (M * hid + 2 * M * D) * 2)
+    mean_, rstd_ = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    rec("linear  fc2+resid+stats", timeit(lambda: K.linear(h, w2, b2, epi=L.EPI_BIAS_RESID, resid=x2, out=y, stats=(mean_, rstd_))), fl1, (M * hid + 2 * M * D) * 2)
+    rec("linear  proj+resid[M,192]x192", timeit(lambda: K.linear(x2, wp, b2, epi=L.EPI_BIAS_RESID, resid=x2, out=y)), 2 * M * D * D, 3 * M * D * 2)
+    rec("linear  gelu_bwd  [M,768]x192", timeit(lambda: K.linear(y, w2t, None, epi=L.EPI_GELU_BWD, u=u, out=h)), fl1, (M * D + 2 * M * hid) * 2)
+    rec("linear  dgrad fc1 [M,192]x768", timeit(lambda: K.linear(h, w1t, None, out=y)), fl1, (M * hid + M * D) * 2)
+    rec("linear  dgrad qkv [M,192]x576", timeit(lambda: K.linear(dq2, wqt, None, out=y)), 2 * M * D * 3 * D, (M * 3 * D + M * D) * 2)
     dw1, db1 = torch.zeros(hid, D, device=dev), torch.zeros(hid, device=dev)
     rec("gemm_tn dW1  [768,192]", timeit(lambda: K.gemm_tn(h, x2, dw1, db1)), fl1)
     dw2, db2 = torch.zeros(D, hid, device=dev), torch.zeros(D, device=dev)

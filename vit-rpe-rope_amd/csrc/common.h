@@ -81,6 +81,17 @@ VITPE_DEV Frag<float> ld_frag(const float* p) {
   return f;
 }
 
+// two separately addressed 16-B halves (fp32 fragments in XOR-swizzled LDS rows)
+VITPE_DEV Frag<float> ld_frag2(const float* p0, const float* p1) {
+  Frag<float> f;
+  f32x4 a = *reinterpret_cast<const f32x4*>(p0);
+  f32x4 b = *reinterpret_cast<const f32x4*>(p1);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { f.v[t] = a[t]; f.v[4 + t] = b[t]; }
+  return f;
+}
+VITPE_DEV Frag<bf16> ld_frag2(const bf16* p0, const bf16*) { return ld_frag(p0); }  // never used for bf16
+
 // ---- transposed fragment from a row-major LDS tile --------------------------------------
 // Lane (c, g) receives elements t<4 : tile[(rb0 + t) * ld + c0 + c]
 //                               t>=4: tile[(rb1 + t-4) * ld + c0 + c]
@@ -212,11 +223,31 @@ VITPE_DEV float group16_max(float v) {
   return v;
 }
 
-VITPE_DEV float gelu_erf(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
+// Exact-erf GELU (nn.GELU default, reference vit.py:111) and its derivative.  erf through
+// Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far inside the 1e-4 parity gate): one rcp, one
+// exp2 and a degree-5 Horner polynomial instead of libm erff's ~35 instructions -- these sit in GEMM
+// epilogues that evaluate them 36 times per lane per tile.  The branch on the sign avoids the
+// 1 + erf(x) cancellation for negative arguments.  cdf = Phi(u), e = exp(-u^2/2).
+VITPE_DEV float gelu_cdf(float u, float& e) {
+  const float ax = fabsf(u) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f);
+  p = fmaf(t, p, -0.284496736f);
+  p = fmaf(t, p, 0.254829592f);
+  p *= t;
+  e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+  const float half = 0.5f * p * e;  // 0.5 * erfc(|x|)
+  return u >= 0.f ? 1.0f - half : half;
+}
+VITPE_DEV float gelu_erf(float u) {
+  float e;
+  return u * gelu_cdf(u, e);
+}
 VITPE_DEV float gelu_erf_grad(float u) {
-  const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * u * u);
-  return cdf + u * pdf;
+  float e;
+  const float cdf = gelu_cdf(u, e);
+  return fmaf(u * 0.39894228040143267794f, e, cdf);
 }
 
 // positional-encoding modes (include/vitpe.h VITPE_PE_*)

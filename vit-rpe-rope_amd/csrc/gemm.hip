@@ -200,6 +200,244 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Panel GEMM (second generation, used whenever N % 192 == 0): one workgroup = 12 waves computes a
+// 144 x 192 output tile (3 x 4 waves, 3 x 3 MFMA tiles each), so for the N = 192 layers a tile is
+// a set of FULL output rows: the activation panel is read from HBM exactly once and row-wise
+// epilogues (LayerNorm statistics of the output) need no second kernel.  K is streamed in 128-byte
+// slabs through two LDS buffers whose rows are XOR-swizzled (16-B slot ^= (row>>1)&7), which makes
+// the ds_read_b128 fragment pattern bank-conflict free without padding; global loads run two
+// slabs ahead in registers.  The epilogue works straight from the accumulators (each lane owns 4
+// consecutive columns of a row).  Row panels are sized by the host so that the grid covers the
+// 256 CUs evenly (M = 33280 -> 256 panels of 130 rows = 2 images).
+struct GemmPanelArgs {
+  const void* A;      // [M,K] T
+  const void* W;      // [N,K] T
+  void* C;            // [M,N] T
+  const float* bias;  // [N] or null
+  const void* R;      // residual [M,N] T (EPI_BIAS_RESID)
+  void* U;            // pre-activation [M,N] T (EPI_BIAS_GELU out / EPI_GELU_BWD in)
+  float* mean_out;    // optional (N == 192 only): LayerNorm statistics of the OUTPUT rows
+  float* rstd_out;
+  int M, N, K;
+  int panel_rows;     // rows per workgroup panel (<= 144)
+  float eps;
+};
+
+template <typename T, int EPI, bool STATS>
+__global__ __launch_bounds__(768) void gemm_panel_kernel(GemmPanelArgs a) {
+  constexpr int BM = 144, BN = 192, ROWB = 128;
+  constexpr int BK = ROWB / (int)sizeof(T), CPS = BK / 32, CHN = CH<T>::n;
+  constexpr int STAGE = (BM + BN) * ROWB;                 // 43008 B
+  constexpr int NCH = (BM + BN) * 8;                      // 16-B chunks per stage
+  constexpr int NIT = (NCH + 767) / 768;                  // 4
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  __shared__ float s_red[BM * 4];
+
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int M = a.M, N = a.N, K = a.K;
+  const int ntn = N / BN;  // column tiles, all done by this workgroup (persistent over the row panel)
+  const int panel = blockIdx.x;
+  const int m0 = panel * a.panel_rows, m_end = min(M, m0 + a.panel_rows);
+  const T* __restrict__ A = reinterpret_cast<const T*>(a.A);
+  const T* __restrict__ W = reinterpret_cast<const T*>(a.W);
+  const Chunk16 zero = {0u, 0u, 0u, 0u};
+
+  f32x4 acc[3][3];  // [nt][mt]
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (K + BK - 1) / BK;
+  const int S = nk * ntn;  // flattened (column tile, K slab) stages
+  auto gload = [&](Chunk16* r, int st) {
+    const int n0 = (st / nk) * BN, k0 = (st % nk) * BK;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int q = tid + 768 * i, row = q >> 3, cc = q & 7;
+      const int kk = k0 + cc * CHN;
+      Chunk16 v = zero;
+      if (q < NCH && kk < K) {
+        if (row < BM) {
+          if (m0 + row < m_end) v = *reinterpret_cast<const Chunk16*>(A + (size_t)(m0 + row) * K + kk);
+        } else {
+          v = *reinterpret_cast<const Chunk16*>(W + (size_t)(n0 + row - BM) * K + kk);
+        }
+      }
+      r[i] = v;
+    }
+  };
+  auto sstore = [&](const Chunk16* r, int buf) {
+    unsigned char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int q = tid + 768 * i, row = q >> 3, cc = q & 7;
+      if (q < NCH) *reinterpret_cast<Chunk16*>(base + row * ROWB + ((cc ^ ((row >> 1) & 7)) << 4)) = r[i];
+    }
+  };
+  auto compute = [&](int buf) {
+    const unsigned char* sA = smem + buf * STAGE;
+    const unsigned char* sW = sA + BM * ROWB;
+#pragma unroll
+    for (int cs = 0; cs < CPS; ++cs) {
+      Frag<T> fw[3], fa[3];
+      // element offset 32cs + 8g  ->  16-B slot(s): bf16 slot = 4cs + g ; fp32 slots = 2g, 2g+1 (cs = 0)
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) {
+        const int row = wn * 48 + 16 * nt + c;
+        const unsigned char* rp = sW + row * ROWB;
+        const int sw = (row >> 1) & 7;
+        if (sizeof(T) == 2) {
+          fw[nt] = ld_frag(reinterpret_cast<const T*>(rp + (((4 * cs + g) ^ sw) << 4)));
+        } else {
+          fw[nt] = ld_frag2(reinterpret_cast<const T*>(rp + (((2 * g) ^ sw) << 4)),
+                            reinterpret_cast<const T*>(rp + (((2 * g + 1) ^ sw) << 4)));
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt) {
+        const int row = wm * 48 + 16 * mt + c;
+        const unsigned char* rp = sA + row * ROWB;
+        const int sw = (row >> 1) & 7;
+        if (sizeof(T) == 2) {
+          fa[mt] = ld_frag(reinterpret_cast<const T*>(rp + (((4 * cs + g) ^ sw) << 4)));
+        } else {
+          fa[mt] = ld_frag2(reinterpret_cast<const T*>(rp + (((2 * g) ^ sw) << 4)),
+                            reinterpret_cast<const T*>(rp + (((2 * g + 1) ^ sw) << 4)));
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) mma(fw[nt], fa[mt], acc[nt][mt]);
+    }
+  };
+
+  T* __restrict__ C = reinterpret_cast<T*>(a.C);
+  // ---- epilogue: the C-layout (each lane 4 columns of 16 different rows) stores at < 1/2 of the
+  // coalesced rate (measured), so the tile goes through LDS: in three passes of 48 rows the owning
+  // waves park their fp32 accumulators in the (now idle) stage buffers, then all 768 threads apply
+  // bias / residual / GELU on 8-column pieces with 16-byte coalesced loads and stores.
+  constexpr int EP_LD = BN + 4;                      // fp32 row stride of the parked tile
+  static_assert(48 * EP_LD * 4 <= 2 * STAGE, "parked tile must fit");
+  float* ep = reinterpret_cast<float*>(smem);
+  auto epilogue = [&](int n0) {
+    const float invN = 1.0f / (float)BN;
+    // coalesced phase: 48 rows x 24 pieces of 8 columns.  Dense mapping (piece q = tid + 768 i) by
+    // default; with STATS every row gets 32 lanes (8 idle) so its statistics reduce with shuffles.
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {           // pass = the mt tile every wave parks (static index!)
+      __syncthreads();                               // stage buffers / previous pass fully consumed
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt)
+        *reinterpret_cast<f32x4*>(ep + (16 * wm + c) * EP_LD + wn * 48 + 16 * nt + 4 * g) = acc[nt][pass];
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int qd = tid + 768 * i;
+        const int row = STATS ? (tid >> 5) + 24 * i : qd / 24;   // parked row: wave-row row/16, c = row%16
+        const int pc = STATS ? (tid & 31) : qd % 24;
+        const bool live = STATS ? (pc < 24) : (qd < 48 * 24);
+        const int gm = m0 + (row >> 4) * 48 + 16 * pass + (row & 15), gn = n0 + pc * 8;
+        const bool ok = live && (gm < m_end);
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = 0.f;
+        if (live) {
+          const f32x4 x = *reinterpret_cast<const f32x4*>(ep + row * EP_LD + pc * 8);
+          const f32x4 y = *reinterpret_cast<const f32x4*>(ep + row * EP_LD + pc * 8 + 4);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { v[t] = x[t]; v[4 + t] = y[t]; }
+        }
+        if (ok) {
+          if (EPI != EPI_GELU_BWD && a.bias != nullptr) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + gn);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.bias + gn + 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { v[t] += b0[t]; v[4 + t] += b1[t]; }
+          }
+          const size_t off = (size_t)gm * N + gn;
+          if (EPI == EPI_BIAS_RESID) {
+            float rv[8];
+#pragma unroll
+            for (int h = 0; h < 8 / CHN; ++h)
+              chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(reinterpret_cast<const T*>(a.R) + off + h * CHN), rv + h * CHN);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] += rv[t];
+          }
+          if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+            for (int h = 0; h < 8 / CHN; ++h)
+              *reinterpret_cast<Chunk16*>(reinterpret_cast<T*>(a.U) + off + h * CHN) = f32_to_chunk<T>(v + h * CHN);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = gelu_erf(v[t]);
+          }
+          if (EPI == EPI_GELU_BWD) {
+            float uv[8];
+#pragma unroll
+            for (int h = 0; h < 8 / CHN; ++h)
+              chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(reinterpret_cast<const T*>(a.U) + off + h * CHN), uv + h * CHN);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] *= gelu_erf_grad(uv[t]);
+          }
+#pragma unroll
+          for (int h = 0; h < 8 / CHN; ++h)
+            *reinterpret_cast<Chunk16*>(C + off + h * CHN) = f32_to_chunk<T>(v + h * CHN);
+        }
+        // LayerNorm statistics of the output rows (values as stored, i.e. rounded to T): the 32 lanes
+        // of a row reduce with shuffles (two-pass variance)
+        if (STATS) {                                 // N == BN enforced by the host
+          float sres = 0.f;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) { v[t] = live ? to_f32(from_f32<T>(v[t])) : 0.f; sres += v[t]; }
+#pragma unroll
+          for (int o = 16; o >= 1; o >>= 1) sres += __shfl_xor(sres, o, 64);
+          const float mean = sres * invN;
+          float sq = 0.f;
+          if (live) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { const float d = v[t] - mean; sq += d * d; }
+          }
+#pragma unroll
+          for (int o = 16; o >= 1; o >>= 1) sq += __shfl_xor(sq, o, 64);
+          if (pc == 0 && gm < m_end) {
+            a.mean_out[gm] = mean;
+            a.rstd_out[gm] = 1.0f / sqrtf(sq * invN + a.eps);
+          }
+        }
+      }
+    }
+    __syncthreads();                                 // parked tile consumed before the next slab is stored
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+
+  // flattened stage loop, register prefetch two stages ahead ACROSS column-tile boundaries: the
+  // first slabs of the next tile are in flight while the current tile's epilogue stores drain
+  Chunk16 ra[NIT], rb[NIT];
+  gload(ra, 0);
+  if (S > 1) gload(rb, 1);
+  for (int st = 0; st < S; st += 2) {
+    sstore(ra, 0);
+    if (st + 2 < S) gload(ra, st + 2);
+    __syncthreads();
+    compute(0);
+    if (st % nk == nk - 1) epilogue((st / nk) * BN);
+    if (st + 1 < S) {
+      sstore(rb, 1);
+      if (st + 3 < S) gload(rb, st + 3);
+      __syncthreads();
+      compute(1);
+      if ((st + 1) % nk == nk - 1) epilogue(((st + 1) / nk) * BN);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Weight gradient: dW[n][k] += sum_m dY[m][n] * X[m][k]   (+ dbias[n] += sum_m dY[m][n])
 // Tile TN=128 (n) x TK (k) per workgroup, 2x2 waves, RPS token rows per stage staged
 // row-major (as they lie in HBM, coalesced) and consumed through transposed LDS reads.
@@ -345,6 +583,57 @@ extern "C" int vitpe_gemm_nt(int dtype, int epi, const void* A, const void* W, v
   if (M == 0) return 0;
   GemmNTArgs a{A, W, C, bias, R, U, ape, cls, M, N, K, P, Ntok};
   return dtype == 1 ? launch_gemm_nt<bf16>(epi, a, stream) : launch_gemm_nt<float>(epi, a, stream);
+}
+
+// panel rows: as many panels as a multiple of the CU count, each <= 144 rows (9 MFMA row tiles)
+static int panel_rows_for(int M) {
+  const int waves = (M + 256 * 144 - 1) / (256 * 144);
+  const int npanels = 256 * waves;
+  int rows = (M + npanels - 1) / npanels;
+  return rows < 16 ? 16 : rows;
+}
+
+template <typename T>
+static int launch_gemm_panel(int epi, GemmPanelArgs a, hipStream_t s) {
+  a.panel_rows = panel_rows_for(a.M);
+  const int npanels = (a.M + a.panel_rows - 1) / a.panel_rows;
+  dim3 grid(npanels), block(768);
+  if (a.mean_out != nullptr) {
+    switch (epi) {
+      case EPI_BIAS: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS, true>), grid, block, 0, s, a); break;
+      case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS_RESID, true>), grid, block, 0, s, a); break;
+      default: return (int)hipErrorInvalidValue;
+    }
+    VITPE_CHECK_LAUNCH();
+  }
+  switch (epi) {
+    case EPI_BIAS: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS, false>), grid, block, 0, s, a); break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS_GELU, false>), grid, block, 0, s, a); break;
+    case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS_RESID, false>), grid, block, 0, s, a); break;
+    case EPI_GELU_BWD: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_GELU_BWD, false>), grid, block, 0, s, a); break;
+    default: return (int)hipErrorInvalidValue;
+  }
+  VITPE_CHECK_LAUNCH();
+}
+
+// C = epi(A W^T) like vitpe_gemm_nt (no EPI_PATCH), plus optional LayerNorm statistics of the output rows
+// (mean_out/rstd_out non-null requires N == 192).  Falls back to the generic tile kernel when N % 192 != 0.
+extern "C" int vitpe_linear(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
+                            const void* R, void* U, float* mean_out, float* rstd_out, float eps, int M, int N, int K,
+                            hipStream_t stream) {
+  VITPE_REQUIRE(A && W && C && M >= 0 && N > 0 && K > 0 && (dtype == 0 || dtype == 1));
+  VITPE_REQUIRE(epi != EPI_PATCH && N % 8 == 0 && K % (dtype == 1 ? 8 : 4) == 0);
+  VITPE_REQUIRE((mean_out == nullptr) == (rstd_out == nullptr));
+  if (epi == EPI_BIAS_RESID) VITPE_REQUIRE(R != nullptr);
+  if (epi == EPI_BIAS_GELU || epi == EPI_GELU_BWD) VITPE_REQUIRE(U != nullptr);
+  if (mean_out) VITPE_REQUIRE(N == 192);
+  if (M == 0) return 0;
+  if (N % 192 != 0) {
+    VITPE_REQUIRE(mean_out == nullptr);
+    return vitpe_gemm_nt(dtype, epi, A, W, C, bias, R, U, nullptr, nullptr, M, N, K, 0, 0, stream);
+  }
+  GemmPanelArgs a{A, W, C, bias, R, U, mean_out, rstd_out, M, N, K, 0, eps};
+  return dtype == 1 ? launch_gemm_panel<bf16>(epi, a, stream) : launch_gemm_panel<float>(epi, a, stream);
 }
 
 template <typename T>

@@ -175,14 +175,14 @@ class TrainEngine:
             K.layernorm_fwd(xin, blk.norm1.weight.data, blk.norm1.bias.data, blk.norm1.eps, out=a["xn1"],
                             mean=a["m1"], rstd=a["r1"])
             K.fused_attention_fwd(a["xn1"], self.Pk(blk.attn.qkv.weight), self.H, self.pe, out=a["a"])
-            K.gemm_nt(a["a"].view(M, D), self.Sh(blk.attn.proj.weight), blk.attn.proj.bias.data, epi=L.EPI_BIAS_RESID,
-                      resid=xin.view(M, D), out=a["xmid"].view(M, D))
+            K.linear(a["a"].view(M, D), self.Sh(blk.attn.proj.weight), blk.attn.proj.bias.data, epi=L.EPI_BIAS_RESID,
+                     resid=xin.view(M, D), out=a["xmid"].view(M, D))
             K.layernorm_fwd(a["xmid"], blk.norm2.weight.data, blk.norm2.bias.data, blk.norm2.eps, out=a["xn2"],
                             mean=a["m2"], rstd=a["r2"])
-            K.gemm_nt(a["xn2"].view(M, D), self.Sh(blk.mlp.fc1.weight), blk.mlp.fc1.bias.data, epi=L.EPI_BIAS_GELU,
-                      u=a["u"], out=a["h"])
-            K.gemm_nt(a["h"], self.Sh(blk.mlp.fc2.weight), blk.mlp.fc2.bias.data, epi=L.EPI_BIAS_RESID,
-                      resid=a["xmid"].view(M, D), out=self.x[l + 1].view(M, D))
+            K.linear(a["xn2"].view(M, D), self.Sh(blk.mlp.fc1.weight), blk.mlp.fc1.bias.data, epi=L.EPI_BIAS_GELU,
+                     u=a["u"], out=a["h"])
+            K.linear(a["h"], self.Sh(blk.mlp.fc2.weight), blk.mlp.fc2.bias.data, epi=L.EPI_BIAS_RESID,
+                     resid=a["xmid"].view(M, D), out=self.x[l + 1].view(M, D))
         K.head_fwd(self.x[-1], mdl.norm.weight.data, mdl.norm.bias.data, mdl.head.weight.data, mdl.head.bias.data,
                    mdl.norm.eps, save=True, logits=self.logits, ws=self.head_ws)
 
@@ -200,20 +200,20 @@ class TrainEngine:
             blk, a = mdl.blocks[l], self.act[l]
             # ---- MLP branch: x_out = xmid + fc2(gelu(fc1(LN2(xmid))))
             dy = cur.view(M, D)
-            K.gemm_nt(dy, self.St(blk.mlp.fc2.weight), None, epi=L.EPI_GELU_BWD, u=a["u"], out=self.du)
+            K.linear(dy, self.St(blk.mlp.fc2.weight), None, epi=L.EPI_GELU_BWD, u=a["u"], out=self.du)
             K.gemm_tn(dy, a["h"], G(blk.mlp.fc2.weight), G(blk.mlp.fc2.bias))
-            K.gemm_nt(self.du, self.St(blk.mlp.fc1.weight), None, out=self.dtmp.view(M, D))
+            K.linear(self.du, self.St(blk.mlp.fc1.weight), None, out=self.dtmp.view(M, D))
             K.gemm_tn(self.du, a["xn2"].view(M, D), G(blk.mlp.fc1.weight), G(blk.mlp.fc1.bias))
             K.layernorm_bwd(self.dtmp, a["xmid"], a["m2"], a["r2"], blk.norm2.weight.data, G(blk.norm2.weight),
                             G(blk.norm2.bias), dres=cur, out=other, workspace=self.ln_ws)
             cur, other = other, cur
             # ---- attention branch: xmid = x_in + proj(attn(LN1(x_in)))
             dy = cur.view(M, D)
-            K.gemm_nt(dy, self.St(blk.attn.proj.weight), None, out=self.dtmp.view(M, D))
+            K.linear(dy, self.St(blk.attn.proj.weight), None, out=self.dtmp.view(M, D))
             K.gemm_tn(dy, a["a"].view(M, D), G(blk.attn.proj.weight), G(blk.attn.proj.bias))
             K.fused_attention_bwd(a["xn1"], self.Pk(blk.attn.qkv.weight), self.dtmp, self.H, self.pe,
                                   out=self.dqkv, **self.pe_grads)
-            K.gemm_nt(self.dqkv.view(M, 3 * D), self.St(blk.attn.qkv.weight), None, out=self.dtmp.view(M, D))
+            K.linear(self.dqkv.view(M, 3 * D), self.St(blk.attn.qkv.weight), None, out=self.dtmp.view(M, D))
             K.gemm_tn(self.dqkv.view(M, 3 * D), a["xn1"].view(M, D), G(blk.attn.qkv.weight), None)
             K.layernorm_bwd(self.dtmp, self.x[l], a["m1"], a["r1"], blk.norm1.weight.data, G(blk.norm1.weight),
                             G(blk.norm1.bias), dres=cur, out=other, workspace=self.ln_ws)

@@ -37,6 +37,24 @@ def gemm_nt(a, w, bias=None, epi=L.EPI_BIAS, resid=None, u=None, out=None):
     return (c, u) if epi == L.EPI_BIAS_GELU else c
 
 
+def linear(a, w, bias=None, epi=L.EPI_BIAS, resid=None, u=None, out=None, stats=None, eps=1e-5):
+    """Second-generation linear (vitpe_linear): epi(A[M,K] W[N,K]^T); `stats=(mean, rstd)` (N == 192)
+    additionally receives the LayerNorm statistics of the output rows.  EPI_BIAS_GELU returns (C, U)."""
+    require_device(a, w, bias, resid, u, out)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.dtype == w.dtype
+    _f32(bias, "bias")
+    c = out if out is not None else torch.empty((M, N), dtype=a.dtype, device=a.device)
+    if epi == L.EPI_BIAS_GELU and u is None:
+        u = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    mean, rstd = stats if stats is not None else (None, None)
+    require_device(mean, rstd)
+    check(lib().vitpe_linear(dtype_code(a.dtype), epi, ptr(a), ptr(w), ptr(c), ptr(bias), ptr(resid), ptr(u),
+                             ptr(mean), ptr(rstd), eps, M, N, K, stream_ptr()), "vitpe_linear")
+    return (c, u) if epi == L.EPI_BIAS_GELU else c
+
+
 def patch_embed_gemm(patches, w, bias, cls, ape, B, P, out=None):
     """tokens[B,P+1,N] from unfolded patches [B*P,K] (vit.py:248-258)."""
     require_device(patches, w, bias, cls, ape, out)

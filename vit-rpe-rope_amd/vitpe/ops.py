@@ -83,9 +83,9 @@ def attention(xn: Tensor, wqkv: Tensor, wproj: Tensor, bproj: Tensor, resid: Opt
     t = _pe_tables(mode, grid, pe_param, inv_freq, degree, per_head)
     a = K.fused_attention_fwd(xn.contiguous(), K.pack_qkv_weights(wqkv.contiguous(), dt, num_heads), num_heads, t)
     if resid is None:
-        y = K.gemm_nt(a.view(B * N, D), _shadow(wproj, dt), bproj, epi=L.EPI_BIAS)
+        y = K.linear(a.view(B * N, D), _shadow(wproj, dt), bproj, epi=L.EPI_BIAS)
     else:
-        y = K.gemm_nt(a.view(B * N, D), _shadow(wproj, dt), bproj, epi=L.EPI_BIAS_RESID,
+        y = K.linear(a.view(B * N, D), _shadow(wproj, dt), bproj, epi=L.EPI_BIAS_RESID,
                       resid=resid.contiguous().view(B * N, D))
     return y.view(B, N, D), a
 
@@ -109,7 +109,7 @@ def _attn_backward(ctx, dy, _da):
     B, N, D = xn.shape
     dy2 = dy.contiguous().view(B * N, D)
     # proj: da = dy Wproj ; dWproj = dy^T a ; dbproj = colsum(dy)
-    da = K.gemm_nt(dy2, _shadow_t(wproj, dt), None, epi=L.EPI_BIAS)
+    da = K.linear(dy2, _shadow_t(wproj, dt), None, epi=L.EPI_BIAS)
     dwproj = torch.zeros_like(wproj)
     dbproj = torch.zeros(D, dtype=torch.float32, device=dy.device)
     K.gemm_tn(dy2, a.view(B * N, D), dwproj, dbproj)
@@ -123,7 +123,7 @@ def _attn_backward(ctx, dy, _da):
                                  dcoeff=dpe if name == "polynomial" else None,
                                  dfreqs=dpe if name == "rope-mixed" else None)
     dq2 = dqkv.view(B * N, 3 * D)
-    dxn = K.gemm_nt(dq2, _shadow_t(wqkv, dt), None, epi=L.EPI_BIAS).view(B, N, D)
+    dxn = K.linear(dq2, _shadow_t(wqkv, dt), None, epi=L.EPI_BIAS).view(B, N, D)
     dwqkv = torch.zeros_like(wqkv)
     K.gemm_tn(dq2, xn.contiguous().view(B * N, D), dwqkv, None)
     return (dxn, dwqkv, dwproj, dbproj, dy if has_resid else None, None, None, None, dpe, None, None, None)
@@ -139,11 +139,11 @@ def mlp(xn: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, resid: Optio
     shp = xn.shape
     D = shp[-1]
     x2 = xn.contiguous().view(-1, D)
-    h, u = K.gemm_nt(x2, _shadow(w1, dt), b1, epi=L.EPI_BIAS_GELU)
+    h, u = K.linear(x2, _shadow(w1, dt), b1, epi=L.EPI_BIAS_GELU)
     if resid is None:
-        y = K.gemm_nt(h, _shadow(w2, dt), b2, epi=L.EPI_BIAS)
+        y = K.linear(h, _shadow(w2, dt), b2, epi=L.EPI_BIAS)
     else:
-        y = K.gemm_nt(h, _shadow(w2, dt), b2, epi=L.EPI_BIAS_RESID, resid=resid.contiguous().view(-1, D))
+        y = K.linear(h, _shadow(w2, dt), b2, epi=L.EPI_BIAS_RESID, resid=resid.contiguous().view(-1, D))
     return y.view(shp), h, u
 
 
@@ -166,10 +166,10 @@ def _mlp_backward(ctx, dy, _dh, _du):
     D = xn.shape[-1]
     dy2 = dy.contiguous().view(-1, D)
     x2 = xn.contiguous().view(-1, D)
-    du = K.gemm_nt(dy2, _shadow_t(w2, dt), None, epi=L.EPI_GELU_BWD, u=u)
+    du = K.linear(dy2, _shadow_t(w2, dt), None, epi=L.EPI_GELU_BWD, u=u)
     dw2, db2 = torch.zeros_like(w2), torch.zeros(w2.shape[0], dtype=torch.float32, device=dy.device)
     K.gemm_tn(dy2, h, dw2, db2)
-    dxn = K.gemm_nt(du, _shadow_t(w1, dt), None, epi=L.EPI_BIAS).view(xn.shape)
+    dxn = K.linear(du, _shadow_t(w1, dt), None, epi=L.EPI_BIAS).view(xn.shape)
     dw1, db1 = torch.zeros_like(w1), torch.zeros(w1.shape[0], dtype=torch.float32, device=dy.device)
     K.gemm_tn(du, x2, dw1, db1)
     return dxn, dw1, db1, dw2, db2, (dy if ctx.has_resid else None)
