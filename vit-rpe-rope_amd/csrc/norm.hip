@@ -144,6 +144,106 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
+// ---- bf16, D <= 256: a row is <= 32 chunks, so every wave works on TWO rows at once (one per
+// 32-lane half) and a block keeps 8 rows in flight; reductions are 5 shuffles inside the half.
+__global__ __launch_bounds__(256) void ln_fwd32_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, bf16* __restrict__ y,
+                                                       float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                       int M, int D, float eps) {
+  const int lane = threadIdx.x & 31, sub = threadIdx.x >> 5;  // 8 half-waves per block
+  const int nch = D / 8;
+  const float invD = 1.0f / (float)D;
+  const bool act = lane < nch;
+  float gm[8], bt[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) { gm[t] = act ? gamma[lane * 8 + t] : 0.f; bt[t] = act ? beta[lane * 8 + t] : 0.f; }
+  for (int row = blockIdx.x * 8 + sub; row < M; row += gridDim.x * 8) {
+    float v[8];
+    float s = 0.f;
+    if (act) {
+      chunk_to_f32<bf16>(*reinterpret_cast<const Chunk16*>(x + (size_t)row * D + lane * 8), v);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) s += v[t];
+    }
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * invD;
+    float s2 = 0.f;
+    if (act) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { const float d = v[t] - mean; s2 += d * d; }
+    }
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+    const float rstd = 1.0f / sqrtf(s2 * invD + eps);
+    if (act) {
+      float o8[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) o8[t] = (v[t] - mean) * rstd * gm[t] + bt[t];
+      *reinterpret_cast<Chunk16*>(y + (size_t)row * D + lane * 8) = f32_to_chunk<bf16>(o8);
+    }
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd32_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                       const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                       const float* __restrict__ gamma, const bf16* __restrict__ dres,
+                                                       bf16* __restrict__ dx, float* __restrict__ dgamma,
+                                                       float* __restrict__ dbeta, int M, int D) {
+  __shared__ float sred[8][2][256];
+  const int lane = threadIdx.x & 31, sub = threadIdx.x >> 5;
+  const int nch = D / 8;
+  const float invD = 1.0f / (float)D;
+  const bool act = lane < nch;
+  float gm[8], ag[8], ab[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) { gm[t] = act ? gamma[lane * 8 + t] : 0.f; ag[t] = 0.f; ab[t] = 0.f; }
+  for (int row = blockIdx.x * 8 + sub; row < M; row += gridDim.x * 8) {
+    float xh[8], g8[8], rv[8];
+    float s1 = 0.f, s2 = 0.f;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    if (act) {
+      float xv[8], dv[8];
+      chunk_to_f32<bf16>(*reinterpret_cast<const Chunk16*>(x + (size_t)row * D + lane * 8), xv);
+      chunk_to_f32<bf16>(*reinterpret_cast<const Chunk16*>(dy + (size_t)row * D + lane * 8), dv);
+      if (dres != nullptr) chunk_to_f32<bf16>(*reinterpret_cast<const Chunk16*>(dres + (size_t)row * D + lane * 8), rv);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        xh[t] = (xv[t] - mean) * rstd;
+        g8[t] = dv[t] * gm[t];
+        s1 += g8[t];
+        s2 += g8[t] * xh[t];
+        ag[t] += dv[t] * xh[t];
+        ab[t] += dv[t];
+      }
+    }
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    s1 *= invD;
+    s2 *= invD;
+    if (act) {
+      float o8[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) o8[t] = rstd * (g8[t] - s1 - xh[t] * s2) + (dres != nullptr ? rv[t] : 0.f);
+      *reinterpret_cast<Chunk16*>(dx + (size_t)row * D + lane * 8) = f32_to_chunk<bf16>(o8);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) { sred[sub][0][lane * 8 + t] = ag[t]; sred[sub][1][lane * 8 + t] = ab[t]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * D; i += 256) {
+    const int which = i / D, d = i % D;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += sred[k][which][d];
+    atomicAdd((which == 0 ? dgamma : dbeta) + d, t);
+  }
+}
+
 // dst0[i] += sum_p partial[p][i] (i < len0) ; dst1[i-len0] += ... (len0 <= i < len0+len1)
 __global__ void reduce_partials_kernel(const float* __restrict__ partial, int nparts, int len0, int len1,
                                        float* __restrict__ dst0, float* __restrict__ dst1) {
@@ -189,6 +289,11 @@ extern "C" int vitpe_layernorm_fwd(int dtype, const void* x, const float* gamma,
   VITPE_REQUIRE((dtype == 0 || dtype == 1) && ln_dims_ok(dtype, D));
   if (M == 0) return 0;
   const int blocks = min((M + 3) / 4, 2048);
+  if (dtype == 1 && D <= 256) {
+    hipLaunchKernelGGL(ln_fwd32_kernel, dim3(min((M + 7) / 8, 1024)), dim3(256), 0, stream, (const bf16*)x, gamma, beta,
+                       (bf16*)y, mean, rstd, M, D, eps);
+    VITPE_CHECK_LAUNCH();
+  }
   if (dtype == 1)
     hipLaunchKernelGGL(ln_fwd_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, (const bf16*)x, gamma, beta,
                        (bf16*)y, mean, rstd, M, D, eps);
@@ -210,6 +315,11 @@ extern "C" int vitpe_layernorm_bwd(int dtype, const void* dy, const void* x, con
   if (M == 0) return 0;
   const int blocks = vitpe_layernorm_bwd_blocks(M);
   const size_t shm = (size_t)4 * 2 * D * sizeof(float);
+  if (dtype == 1 && D <= 256) {
+    hipLaunchKernelGGL(ln_bwd32_kernel, dim3(min((M + 7) / 8, 512)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)x,
+                       mean, rstd, gamma, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, M, D);
+    VITPE_CHECK_LAUNCH();
+  }
   if (dtype == 1)
     hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3(blocks), dim3(256), shm, stream, (const bf16*)dy, (const bf16*)x,
                        mean, rstd, gamma, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, M, D);
