@@ -156,6 +156,12 @@ int vitpe_adamw_step(float* p, float* g, float* m, float* v, void* shadow_bf16, 
                      long long n, int zero_grad, vitpe_stream_t stream);
 int vitpe_cast(int dtype, const float* src, void* dst, long long n, vitpe_stream_t stream);
 int vitpe_transpose_cast(int dtype, const float* src, void* dst, int R, int C, vitpe_stream_t stream);
+/* every weight shadow of the model in one launch.  desc: device array of ndesc records
+ * {int64 src_off (elements into flat), int64 dst_off (elements into dst_base), int32 R, C, tile0,
+ *  kind (0 = transpose, 1 = vitpe_pack_qkv_weights layout), HD, pad}; tile0 = running sum of
+ * ceil(R/32)*ceil(C/32); total_tiles = that sum over all records.                               */
+int vitpe_refresh_shadows(int dtype, const float* flat, void* dst_base, const void* desc, int ndesc,
+                          int total_tiles, vitpe_stream_t stream);
 
 /* ---- primitive self-test (MFMA operand maps, transposed LDS read) ------------------------- */
 int vitpe_selftest_mma(int dtype, const void* A, const void* Bt, const void* Brow, float* C_row,

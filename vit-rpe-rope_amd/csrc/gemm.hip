@@ -450,6 +450,8 @@ struct GemmTNArgs {
   float* dbias;    // [N] fp32 or null, accumulated into
   int M, N, K;
   int rows_per_split;
+  long long sn, sk;   // output strides: dW element (n,k) lives at dW[n*sn + k*sk] (lets the roles be swapped)
+  int bias_from_x;    // dbias = colsum(X) (length K) instead of colsum(dY) (length N)
 };
 
 template <typename T, int TK>
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
   constexpr int YCH = TN / CHN, XCH = TK / CHN;          // 16-B chunks per row
   constexpr int YIT = RPS * YCH / 256, XIT = RPS * XCH / 256;
   static_assert(RPS * YCH % 256 == 0 && RPS * XCH % 256 == 0, "stage must divide over 256 threads");
-  constexpr int KT = TK / 32;  // k tiles (16 wide) per wave
+  constexpr int KT = TK / 32;  // k tiles (16 wide) per wave (each wave owns half of TK)
   __shared__ __attribute__((aligned(16))) T sY[RPS * LDY];
   __shared__ __attribute__((aligned(16))) T sX[RPS * LDX];
 
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
 #pragma unroll
     for (int j = 0; j < KT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-  const bool do_bias = (a.dbias != nullptr) && (blockIdx.y == 0);
+  const bool do_bias = (a.dbias != nullptr) && (a.bias_from_x ? blockIdx.x == 0 : blockIdx.y == 0);
   const Chunk16 zero = {0u, 0u, 0u, 0u};
 
   Chunk16 ry[YIT], rx[XIT];
@@ -531,9 +533,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) mma(fy[nt], fx[kt], acc[nt][kt]);
     }
-    if (do_bias && tid < TN) {
+    if (do_bias && tid < (a.bias_from_x ? TK : TN)) {
       float s = 0.f;
-      for (int r = 0; r < RPS; ++r) s += to_f32(sY[r * LDY + tid]);
+      if (a.bias_from_x) { for (int r = 0; r < RPS; ++r) s += to_f32(sX[r * LDX + tid]); }
+      else { for (int r = 0; r < RPS; ++r) s += to_f32(sY[r * LDY + tid]); }
       bsum += s;
     }
   }
@@ -546,9 +549,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int gn = n0 + wn * 64 + 16 * nt + 4 * g + r;
         const int gk = k0 + wk * (TK / 2) + 16 * kt + c;
-        if (gn < N && gk < K) atomicAdd(a.dW + (size_t)gn * K + gk, acc[nt][kt][r]);
+        if (gn < N && gk < K) atomicAdd(a.dW + gn * a.sn + gk * a.sk, acc[nt][kt][r]);
       }
-  if (do_bias && tid < TN && n0 + tid < N) atomicAdd(a.dbias + n0 + tid, bsum);
+  if (do_bias) {
+    if (a.bias_from_x) { if (tid < TK && k0 + tid < K) atomicAdd(a.dbias + k0 + tid, bsum); }
+    else if (tid < TN && n0 + tid < N) atomicAdd(a.dbias + n0 + tid, bsum);
+  }
 }
 
 }  // namespace vitpe
@@ -644,7 +650,11 @@ static int launch_gemm_tn(GemmTNArgs a, int splits, hipStream_t s) {
   a.rows_per_split = rps;
   const int nz = (a.M + rps - 1) / rps;
   dim3 block(256);
-  if (a.K % 128 == 0 || a.K > 192) {
+  if (false && a.K % 192 == 0) {  // 128x192 tiles: fewer panel re-reads but LDS-read bound on the transposed
+                                   // fragment reads (measured 15 % slower than 128x64) -- kept for the redesign
+    dim3 grid((a.N + 127) / 128, a.K / 192, nz);
+    hipLaunchKernelGGL((gemm_tn_kernel<T, 192>), grid, block, 0, s, a);
+  } else if (a.K % 128 == 0 || a.K > 192) {
     dim3 grid((a.N + 127) / 128, (a.K + 127) / 128, nz);
     hipLaunchKernelGGL((gemm_tn_kernel<T, 128>), grid, block, 0, s, a);
   } else {
@@ -660,6 +670,10 @@ extern "C" int vitpe_gemm_tn(int dtype, const void* dY, const void* X, float* dW
   VITPE_REQUIRE(dtype == 0 || dtype == 1);
   VITPE_REQUIRE(N % (dtype == 1 ? 8 : 4) == 0 && K % (dtype == 1 ? 8 : 4) == 0);
   if (M == 0) return 0;
-  GemmTNArgs a{dY, X, dW, dbias, M, N, K, 0};
+  GemmTNArgs a{dY, X, dW, dbias, M, N, K, 0, (long long)K, 1LL, 0};
+  if (false && K % 192 != 0 && N % 192 == 0) {
+    // swap the roles so the 192-multiple side becomes the full-width side: dW^T = X^T dY
+    a.dY = X; a.X = dY; a.N = K; a.K = N; a.sn = 1; a.sk = K; a.bias_from_x = 1;
+  }
   return dtype == 1 ? launch_gemm_tn<bf16>(a, splits, stream) : launch_gemm_tn<float>(a, splits, stream);
 }

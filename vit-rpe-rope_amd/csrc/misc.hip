@@ -312,6 +312,50 @@ __global__ void transpose_cast_kernel(const float* __restrict__ src, T* __restri
   }
 }
 
+// All weight shadows of the model in ONE launch (after the optimizer step): a descriptor per matrix,
+// each workgroup handles one 32x32 tile.  kind 0: dst[c][r] = src[r][c] (transposed shadow for the
+// data-gradient GEMMs); kind 1: fragment-major packing of attn.qkv.weight (see pack_qkv_kernel).
+struct ShadowDesc { long long src_off, dst_off; int R, C, tile0, kind, HD, pad; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void refresh_shadows_kernel(const float* __restrict__ flat, T* __restrict__ dst_base,
+                                                              const ShadowDesc* __restrict__ desc, int ndesc) {
+  __shared__ float tile[32][33];
+  int d = 0;
+  for (int i = 1; i < ndesc; ++i)
+    if ((int)blockIdx.x >= desc[i].tile0) d = i;   // wave-uniform scan of a handful of descriptors
+  const ShadowDesc ds = desc[d];
+  const int t = blockIdx.x - ds.tile0;
+  const int tc = (ds.C + 31) / 32;
+  const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+  const float* src = flat + ds.src_off;
+  T* dst = dst_base + ds.dst_off;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < ds.R && c < ds.C) ? src[(size_t)r * ds.C + c] : 0.f;
+  }
+  __syncthreads();
+  if (ds.kind == 0) {
+    for (int i = ty; i < 32; i += 8) {
+      const int c = c0 + i, r = r0 + tx;
+      if (c < ds.C && r < ds.R) dst[(size_t)c * ds.R + r] = from_f32<T>(tile[tx][i]);
+    }
+  } else {
+    // W[3D, D]: row = mat*D + h*HD + 16nt + cc ; col = 32ks + 8g + e  ->  block (h,mat,nt,ks), lane 16g+cc, e
+    const int D = ds.C, HD = ds.HD, NT = HD / 16, KS = D / 32;
+    for (int i = ty; i < 32; i += 8) {
+      const int r = r0 + i, c = c0 + tx;
+      if (r < ds.R && c < ds.C) {
+        const int mat = r / D, rr = r % D, h = rr / HD, nt = (rr % HD) / 16, cc = rr % 16;
+        const int ks = c / 32, g = (c % 32) / 8, e = c % 8;
+        const size_t blk = (((size_t)(h * 3 + mat) * NT + nt) * KS + ks);
+        dst[(blk * 64 + 16 * g + cc) * 8 + e] = from_f32<T>(tile[i][tx]);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Self-tests of the primitives every kernel relies on (run by tests/ on the GPU box):
 //  C[16x16] = A[16x32] * B[32x16] through mma<T>, with A given row-major [16][32] and B either
@@ -463,6 +507,18 @@ extern "C" int vitpe_transpose_cast(int dtype, const float* src, void* dst, int 
   dim3 grid((C + 31) / 32, (R + 31) / 32), block(32, 8);
   if (dtype == 1) hipLaunchKernelGGL(transpose_cast_kernel<bf16>, grid, block, 0, st, src, (bf16*)dst, R, C);
   else hipLaunchKernelGGL(transpose_cast_kernel<float>, grid, block, 0, st, src, (float*)dst, R, C);
+  VITPE_CHECK_LAUNCH();
+}
+
+extern "C" int vitpe_refresh_shadows(int dtype, const float* flat, void* dst_base, const void* desc, int ndesc,
+                                     int total_tiles, hipStream_t st) {
+  VITPE_REQUIRE(flat && dst_base && desc && ndesc > 0 && total_tiles > 0 && (dtype == 0 || dtype == 1));
+  if (dtype == 1)
+    hipLaunchKernelGGL(refresh_shadows_kernel<bf16>, dim3(total_tiles), dim3(256), 0, st, flat, (bf16*)dst_base,
+                       (const ShadowDesc*)desc, ndesc);
+  else
+    hipLaunchKernelGGL(refresh_shadows_kernel<float>, dim3(total_tiles), dim3(256), 0, st, flat, (float*)dst_base,
+                       (const ShadowDesc*)desc, ndesc);
   VITPE_CHECK_LAUNCH();
 }
 

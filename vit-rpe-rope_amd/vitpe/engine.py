@@ -79,15 +79,40 @@ class TrainEngine:
         self.hp = torch.zeros(16, **f)
         self.hp[:5] = torch.tensor([lr, betas[0], betas[1], eps, wd], **f)
         self.hp[8] = 1.0 / self.world
-        # transposed shadows of the GEMM weights used by the data-gradient GEMMs
+        # transposed shadows of the GEMM weights (data-gradient GEMMs) and fragment-major packed qkv
+        # weights (attention kernels): one flat buffer, refreshed by ONE batched kernel per step
         self._st: Dict[int, torch.Tensor] = {}
-        self._pk: Dict[int, torch.Tensor] = {}   # fragment-major packed qkv weights (attention kernels)
+        self._pk: Dict[int, torch.Tensor] = {}
         self._gemm_weights: List[nn.Parameter] = []
+        recs, off, tile0 = [], 0, 0
+        def add(w, kind):
+            nonlocal off, tile0
+            R, C = w.shape
+            recs.append((self._off[id(w)], off, R, C, tile0, kind, self.D // self.H, 0))
+            o = off
+            off += (R * C + ALIGN - 1) // ALIGN * ALIGN
+            tile0 += ((R + 31) // 32) * ((C + 31) // 32)
+            return o
+        spans = []
         for blk in self.model.blocks:
             for w in (blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight):
                 self._gemm_weights.append(w)
-                self._st[id(w)] = torch.empty((w.shape[1], w.shape[0]), dtype=self.T, device=self.dev)
-            self._pk[id(blk.attn.qkv.weight)] = torch.empty(blk.attn.qkv.weight.shape, dtype=self.T, device=self.dev)
+                spans.append((w, 0, add(w, 0)))
+            spans.append((blk.attn.qkv.weight, 1, add(blk.attn.qkv.weight, 1)))
+        self._shadow_flat = torch.empty(off, dtype=self.T, device=self.dev)
+        for w, kind, o in spans:
+            R, C = w.shape
+            if kind == 0:
+                self._st[id(w)] = self._shadow_flat[o:o + R * C].view(C, R)
+            else:
+                self._pk[id(w)] = self._shadow_flat[o:o + R * C].view(R, C)
+        import numpy as np
+        rec = np.zeros(len(recs), dtype=np.dtype([("src", "<i8"), ("dst", "<i8"), ("R", "<i4"), ("C", "<i4"),
+                                                   ("tile0", "<i4"), ("kind", "<i4"), ("HD", "<i4"), ("pad", "<i4")]))
+        for i, r in enumerate(recs):
+            rec[i] = r
+        self._desc = torch.from_numpy(rec.view(np.uint8).copy()).to(self.dev)
+        self._ndesc, self._ntiles = len(recs), tile0
         self.refresh_shadows()
 
     def Pm(self, prm):  # fp32 master view
@@ -112,10 +137,7 @@ class TrainEngine:
     def refresh_shadows(self, cast_flat=True):
         if self.T == torch.bfloat16 and cast_flat:
             K.cast(self.flat_p, torch.bfloat16, out=self.flat_s)
-        for w in self._gemm_weights:
-            K.transpose_cast(w.data, self.T, out=self._st[id(w)])
-        for blk in self.model.blocks:
-            K.pack_qkv_weights(blk.attn.qkv.weight.data, self.T, self.H, out=self._pk[id(blk.attn.qkv.weight)])
+        K.refresh_shadows(self.flat_p, self._shadow_flat, self._desc, self._ndesc, self._ntiles)
 
     def set_lr(self, lr: float):
         self.hp[0] = lr

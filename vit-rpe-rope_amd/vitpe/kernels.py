@@ -69,7 +69,8 @@ def patch_embed_gemm(patches, w, bias, cls, ape, B, P, out=None):
 
 
 def wgrad_splits(M, N, K):
-    tiles = ((N + 127) // 128) * ((K + 127) // 128 if (K % 128 == 0 or K > 192) else (K + 63) // 64)
+    if True:
+        tiles = ((N + 127) // 128) * ((K + 127) // 128 if (K % 128 == 0 or K > 192) else (K + 63) // 64)
     return max(1, min(64, SPLITS_TARGET_WGS // max(tiles, 1), (M + 255) // 256))
 
 
@@ -327,6 +328,12 @@ def transpose_cast(src, dtype, out=None):
     o = out if out is not None else torch.empty((C, R), dtype=dtype, device=src.device)
     check(lib().vitpe_transpose_cast(dtype_code(dtype), ptr(src), ptr(o), R, C, stream_ptr()), "vitpe_transpose_cast")
     return o
+
+
+def refresh_shadows(flat, dst_base, desc, ndesc, total_tiles):
+    require_device(flat, dst_base, desc)
+    check(lib().vitpe_refresh_shadows(dtype_code(dst_base.dtype), ptr(flat), ptr(dst_base), ptr(desc), ndesc, total_tiles,
+                                      stream_ptr()), "vitpe_refresh_shadows")
 
 
 def selftest_mma(a, bt, brow):
