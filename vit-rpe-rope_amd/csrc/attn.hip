@@ -371,6 +371,8 @@ __global__ __launch_bounds__(384 * IPW) void attn_fwd_kernel(AttnArgs a) {
       }
       const float inv = __builtin_amdgcn_rcpf(l);
       const int i = 16 * it + c;
+      // direct C-layout stores: they are asynchronous and fully overlapped here (an LDS-staged
+      // coalesced flush was measured: no gain, one more barrier)
       if (live && (it < MT - 1 || i < N)) {
 #pragma unroll
         for (int dt = 0; dt < C::NT; ++dt)
@@ -399,6 +401,10 @@ __global__ __launch_bounds__(384) void attn_bwd_kernel(AttnArgs a) {
   __shared__ float s_dtab[KM == KM_RELATIVE ? C::H * C::TABLD : 4];  // relative-table gradient of this image
   __shared__ float s_dcoef[C::H * (C::MAXDEG + 1)];
   __shared__ float s_dfreq[2 * C::H * (HD / 2)];
+  // d_qkv of the pass's heads, [mat][token][HPP*HD] so that a token row holds HPP*HD contiguous
+  // elements per matrix: flushed with coalesced 16-B stores (the C-layout stores run at < 1/2 rate)
+  constexpr int SLD = HPP * HD + Pad<T>::elems;
+  __shared__ __attribute__((aligned(16))) T s_dq[3 * C::NP * SLD];
 
   const int N = C::ntok(a);
   const int b = blockIdx.x;
@@ -567,12 +573,10 @@ __global__ __launch_bounds__(384) void attn_bwd_kernel(AttnArgs a) {
           }
         }
       }
-      if (qvalid) {
 #pragma unroll
-        for (int dt = 0; dt < C::NT; ++dt)
-          st4(dq + (size_t)i * 3 * D + h * HD + 16 * dt + 4 * g, dqa[dt][0] * a.scale, dqa[dt][1] * a.scale,
-              dqa[dt][2] * a.scale, dqa[dt][3] * a.scale);
-      }
+      for (int dt = 0; dt < C::NT; ++dt)
+        st4(s_dq + (0 * C::NP + i) * SLD + hh * HD + 16 * dt + 4 * g, dqa[dt][0] * a.scale, dqa[dt][1] * a.scale,
+            dqa[dt][2] * a.scale, dqa[dt][3] * a.scale);
     }
     __syncthreads();
 
@@ -664,15 +668,24 @@ __global__ __launch_bounds__(384) void attn_bwd_kernel(AttnArgs a) {
           }
         }
       }
-      if (kvalid) {
 #pragma unroll
-        for (int dt = 0; dt < C::NT; ++dt) {
-          st4(dq + (size_t)j * 3 * D + D + h * HD + 16 * dt + 4 * g, dka[dt][0], dka[dt][1], dka[dt][2], dka[dt][3]);
-          st4(dq + (size_t)j * 3 * D + 2 * D + h * HD + 16 * dt + 4 * g, dva[dt][0], dva[dt][1], dva[dt][2], dva[dt][3]);
-        }
+      for (int dt = 0; dt < C::NT; ++dt) {
+        st4(s_dq + (1 * C::NP + j) * SLD + hh * HD + 16 * dt + 4 * g, dka[dt][0], dka[dt][1], dka[dt][2], dka[dt][3]);
+        st4(s_dq + (2 * C::NP + j) * SLD + hh * HD + 16 * dt + 4 * g, dva[dt][0], dva[dt][1], dva[dt][2], dva[dt][3]);
       }
     }
     __syncthreads();
+    {  // coalesced flush: per token row and matrix, nh*HD contiguous elements
+      constexpr int CPH = HD / CHN;
+      const int nh = min(HPP, C::H - h0);
+      for (int q = threadIdx.x; q < 3 * N * nh * CPH; q += 384) {
+        const int mat = q / (N * nh * CPH), rem = q % (N * nh * CPH);
+        const int row = rem / (nh * CPH), cc = rem % (nh * CPH);
+        *reinterpret_cast<Chunk16*>(dq + (size_t)row * 3 * D + mat * D + h0 * HD + cc * CHN) =
+            *reinterpret_cast<const Chunk16*>(s_dq + (mat * C::NP + row) * SLD + cc * CHN);
+      }
+    }
+    // (the next pass writes s_dq only after its projection barrier: no extra barrier needed)
   }
 
   // ---- flush this image's positional-parameter gradients ----------------------------------
