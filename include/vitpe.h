@@ -68,6 +68,13 @@ int vitpe_fused_attention_fwd(int dtype, const void* xn, const void* wqkv, void*
                               int D, int HD, int mode, const float* cos, const float* sin,
                               const float* table, const float* coeff, int grid, int degree,
                               int coeff_per_head, vitpe_stream_t stream);
+/* Same with the preceding LayerNorm fused into the token staging: x = RAW tokens, mean/rstd their
+ * row statistics, xn_out (nullable) receives LayerNorm(x) (needed by the backward pass).          */
+int vitpe_fused_attention_fwd_ln(int dtype, const void* x, const float* gamma, const float* beta,
+                                 const float* mean, const float* rstd, void* xn_out, const void* wqkv,
+                                 void* out, int B, int N, int D, int HD, int mode, const float* cos,
+                                 const float* sin, const float* table, const float* coeff, int grid,
+                                 int degree, int coeff_per_head, vitpe_stream_t stream);
 /* Backward of the above (the reference relies on autograd).  dqkv [B,N,3D] T is the gradient of
  * the qkv Linear's output (columns [q|k|v] x heads, like the forward's qkv buffer); the caller
  * finishes with dxn = dqkv Wqkv (vitpe_gemm_nt on the transposed shadow) and dWqkv = dqkv^T xn
@@ -96,12 +103,25 @@ int vitpe_gemm_nt(int dtype, int epi, const void* A, const void* W, void* C, con
 int vitpe_linear(int dtype, int epi, const void* A, const void* W, void* C, const float* bias,
                  const void* R, void* U, float* mean_out, float* rstd_out, float eps, int M, int N,
                  int K, vitpe_stream_t stream);
+/* LayerNorm fused into its neighbours (removes the stand-alone LayerNorm passes of vit.py:113,116):
+ *  vitpe_linear_ln    : C = epi(LN(X) W^T), X raw [M,K] with row statistics mean/rstd (e.g. the stats
+ *                       output of vitpe_linear); xn_out (nullable) receives LN(X) for the backward pass;
+ *                       epi in {BIAS, BIAS_GELU}, N % 192 == 0.
+ *  vitpe_linear_lnbwd : dx = dres + LN'(dY Wt^T) for the LayerNorm with input rows x [M,192]; dgamma/dbeta
+ *                       accumulated.  (data gradient of qkv / fc1 + LayerNorm backward + residual add)      */
+int vitpe_linear_ln(int dtype, int epi, const void* X, const float* gamma, const float* beta,
+                    const float* mean, const float* rstd, void* xn_out, const void* W, void* C,
+                    const float* bias, void* U, int M, int N, int K, vitpe_stream_t stream);
+int vitpe_linear_lnbwd(int dtype, const void* dY, const void* Wt, void* dx, const void* x, const float* mean,
+                       const float* rstd, const float* gamma, const void* dres, float* dgamma, float* dbeta,
+                       int M, int K, vitpe_stream_t stream);
 /* vitpe_gemm_tn: dW[N,K] += dY[M,N]^T X[M,K] ; dbias[N] += colsum(dY) (NULL to skip).  fp32
  * outputs, accumulated with atomics over `splits` token slices.                             */
 int vitpe_gemm_tn(int dtype, const void* dY, const void* X, float* dW, float* dbias, int M, int N,
                   int K, int splits, vitpe_stream_t stream);
 
 /* ---- LayerNorm (nn.LayerNorm(d), eps 1e-5: vit.py:113,116,210) ------------------------------ */
+/* y == NULL: row statistics only (mean and rstd required) */
 int vitpe_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y,
                         float* mean, float* rstd, int M, int D, float eps, vitpe_stream_t stream);
 int vitpe_layernorm_bwd_blocks(int M); /* workspace = blocks * 2 * D floats */

@@ -122,6 +122,51 @@ def test_linear_panel_kernel_all_epilogues(K, dt, M, N, K_):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_layernorm_fused_into_linear_and_attention(K, dt):
+    """LN prologue of vitpe_linear_ln, LN-backward epilogue of vitpe_linear_lnbwd, LN inside the attention staging."""
+    M, D, hid = 397, 192, 768
+    x, g, b = rnd(M, D, seed=1, scale=2.0) + 0.3, 1 + 0.1 * rnd(D, seed=2), 0.1 * rnd(D, seed=3)
+    w1, b1 = rnd(hid, D, seed=4, scale=0.2), rnd(hid, seed=5)
+    xq = q(x, dt)
+    xn_ref = torch.nn.functional.layer_norm(xq, (D,), g, b, 1e-5)
+    X = dev(x, DT[dt])
+    mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    K.layernorm_fwd(X, dev(g), dev(b), mean=mean, rstd=rstd, stats_only=True)
+    assert rel_err(mean.cpu(), xq.mean(-1)) < 1e-5
+    xn_out = torch.empty_like(X)
+    h, u = K.linear_ln(X, dev(g), dev(b), mean, rstd, dev(w1, DT[dt]), dev(b1), epi=1, xn_out=xn_out)
+    assert rel_err(xn_out.float().cpu(), xn_ref) < tol(dt)
+    u_ref = q(xn_ref, dt) @ q(w1, dt).t() + b1
+    assert rel_err(u.float().cpu(), u_ref) < tol(dt)
+    assert rel_err(h.float().cpu(), torch.nn.functional.gelu(u_ref)) < tol(dt)
+    # backward: dx = dres + LN'(dy @ wt^T)
+    Kd = 576
+    dy, wt, dres = rnd(M, Kd, seed=6), rnd(D, Kd, seed=7, scale=0.2), rnd(M, D, seed=8)
+    xr = xq.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5)
+    dxn = q(q(dy, dt) @ q(wt, dt).t(), dt)
+    yr.backward(dxn)
+    dgam, dbet = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    dx = K.linear_lnbwd(dev(dy, DT[dt]), dev(wt, DT[dt]), X, mean, rstd, dev(g), dev(dres, DT[dt]), dgam, dbet)
+    assert rel_err(dx.float().cpu(), xr.grad + q(dres, dt)) < tol(dt)
+    assert rel_err(dgam.cpu(), gr.grad) < tol(dt)
+    assert rel_err(dbet.cpu(), br.grad) < tol(dt)
+    # attention with LN in the staging == attention on pre-normalised tokens
+    B, N, H = 3, 65, 6
+    xa = rnd(B, N, D, seed=9, scale=2.0)
+    wq = K.pack_qkv_weights(dev(rnd(3 * D, D, seed=10, scale=0.3)), DT[dt], H)
+    t = device_pe(K, "rope-axial", {"inv_freq": O.rope_axial_inv_freq(32, 100.0)}, H, 8)
+    Xa = dev(xa, DT[dt])
+    xn, m_, r_ = K.layernorm_fwd(Xa, dev(g), dev(b))
+    ref = K.fused_attention_fwd(xn, wq, H, t)
+    xn2 = torch.empty_like(Xa)
+    out = K.fused_attention_fwd(Xa, wq, H, t, ln=(dev(g), dev(b), m_, r_), xn_out=xn2)
+    assert torch.equal(xn2, xn)
+    assert rel_err(out.float().cpu(), ref.float().cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("M,N,K_,splits", [(195, 96, 96, 1), (650, 576, 192, 4), (333, 192, 768, 3), (260, 192, 48, 2), (200, 96, 384, 5)])
 def test_gemm_tn_wgrad(K, dt, M, N, K_, splits):
     dy, x = rnd(M, N, seed=1), rnd(M, K_, seed=2)

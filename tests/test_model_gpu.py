@@ -172,6 +172,23 @@ def test_engine_fp32_matches_oracle_and_autograd_path(tag, extra):
         assert rel_err(p.grad.cpu(), ref) < 1e-3, n
 
 
+@pytest.mark.parametrize("fuse", [False, "fwd", True])
+def test_engine_layernorm_fusion_variants_agree_with_oracle(fuse):
+    """Full-width (d=192) engine with stand-alone / forward-fused / fully fused LayerNorm, fp32 vs the oracle."""
+    from vitpe.engine import TrainEngine
+    cfg, model = build("rope-mixed", {}, dict(depth=2))
+    params = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+    images, labels = O.closed_form_batch(cfg, 5, salt=2)
+    ref_logits, ref_loss, ref_grads = O.loss_and_grads(cfg, params, images, labels)
+    eng = TrainEngine(model, 5, compute_dtype=torch.float32, use_graph=False, fuse_ln=fuse)
+    assert eng.fuse_ln == (fuse is not False) and eng.fuse_ln_bwd == (fuse is True)
+    eng.images.copy_(images.cuda()); eng.labels.copy_(labels.cuda())
+    eng.forward_backward()
+    assert rel_err(eng.logits.cpu(), ref_logits) < 1e-4
+    for n, p in model.named_parameters():
+        assert rel_err(p.grad.cpu(), ref_grads[n]) < 1e-3, n
+
+
 @pytest.mark.parametrize("tag", ["rope-axial", "relative"])
 def test_engine_adamw_trajectory_and_graph_replay(golden, tag):
     """5 AdamW steps on a fixed batch vs the reference's trajectory; eager and captured-graph

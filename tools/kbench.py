@@ -78,6 +78,15 @@ def main():
     rec("linear  gelu_bwd  [M,768]x192", timeit(lambda: K.linear(y, w2t, None, epi=L.EPI_GELU_BWD, u=u, out=h)), fl1, (M * D + 2 * M * hid) * 2)
     rec("linear  dgrad fc1 [M,192]x768", timeit(lambda: K.linear(h, w1t, None, out=y)), fl1, (M * hid + M * D) * 2)
     rec("linear  dgrad qkv [M,192]x576", timeit(lambda: K.linear(dq2, wqt, None, out=y)), 2 * M * D * 3 * D, (M * 3 * D + M * D) * 2)
+    gam, bet = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+    K.layernorm_fwd(x2, gam, bet, mean=mean_, rstd=rstd_, stats_only=True)
+    rec("stats only", timeit(lambda: K.layernorm_fwd(x2, gam, bet, mean=mean_, rstd=rstd_, stats_only=True)), 0, M * D * 2)
+    xno = torch.empty_like(x2)
+    rec("linear_ln fc1+gelu (+xn out)", timeit(lambda: K.linear_ln(x2, gam, bet, mean_, rstd_, w1, b1, epi=L.EPI_BIAS_GELU, u=u, out=h, xn_out=xno)), fl1)
+    dgm, dbt2 = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    rec("linear_lnbwd dgrad fc1 K=768", timeit(lambda: K.linear_lnbwd(h, w1t, x2, mean_, rstd_, gam, x2, dgm, dbt2, out=y)), fl1)
+    rec("linear_lnbwd dgrad qkv K=576", timeit(lambda: K.linear_lnbwd(dq2, wqt, x2, mean_, rstd_, gam, x2, dgm, dbt2, out=y)), 2 * M * D * 3 * D)
+    rec("attn_fwd rope + LN (+xn out)", timeit(lambda: K.fused_attention_fwd(xn, wqkv, H, pe, out=out, ln=(gam, bet, mean_, rstd_), xn_out=dout)), fl_attn)
     dw1, db1 = torch.zeros(hid, D, device=dev), torch.zeros(hid, device=dev)
     rec("gemm_tn dW1  [768,192]", timeit(lambda: K.gemm_tn(h, x2, dw1, db1)), fl1)
     dw2, db2 = torch.zeros(D, hid, device=dev), torch.zeros(D, device=dev)

@@ -44,6 +44,14 @@ struct AttnArgs {
   int B, N;
   int mode, grid, degree, coeff_per_head;
   float scale;
+  // optional fused LayerNorm (reference vit.py:113,122): xn = (x - mean[row]) * rstd[row] * gamma + beta is
+  // applied while staging; `xn` then points at the RAW tokens and xn_out (nullable) receives the
+  // normalised tokens for the backward pass
+  const float* ln_gamma;
+  const float* ln_beta;
+  const float* ln_mean;
+  const float* ln_rstd;
+  void* xn_out;
   unsigned long long* census;  // debug: per workgroup {hw_id | xcc_id<<32, t_start, t_end} or null
 };
 
@@ -143,6 +151,27 @@ VITPE_DEV void stage_tokens(const AttnArgs& a, int b, T* xs, T* hbuf, int hbuf_e
     const int q = tid + it * nthreads, row = q / DCH, cc = q % DCH;
     v[it] = zero;
     if (q < TOTAL && row < N && cc * CHN < D) v[it] = *reinterpret_cast<const Chunk16*>(xg + (size_t)row * D + cc * CHN);
+  }
+  if (a.ln_gamma != nullptr) {  // fused LayerNorm on the way in (uniform branch)
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int q = tid + it * nthreads, row = q / DCH, cc = q % DCH;
+      if (q < TOTAL && row < N && cc * CHN < D) {
+        const float mean = a.ln_mean[(size_t)b * N + row], rstd = a.ln_rstd[(size_t)b * N + row];
+        float f[CHN];
+        chunk_to_f32<T>(v[it], f);
+#pragma unroll
+        for (int h4 = 0; h4 < CHN / 4; ++h4) {
+          const f32x4 gq = *reinterpret_cast<const f32x4*>(a.ln_gamma + cc * CHN + 4 * h4);
+          const f32x4 bq = *reinterpret_cast<const f32x4*>(a.ln_beta + cc * CHN + 4 * h4);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) f[4 * h4 + t] = (f[4 * h4 + t] - mean) * rstd * gq[t] + bq[t];
+        }
+        v[it] = f32_to_chunk<T>(f);
+        if (a.xn_out != nullptr)
+          *reinterpret_cast<Chunk16*>(reinterpret_cast<T*>(a.xn_out) + ((size_t)b * N + row) * D + cc * CHN) = v[it];
+      }
+    }
   }
   // zero what must read as zero and is never written again (whole buffer when zero_all, else the caller's tails)
   for (int q = tid; q < hbuf_elems / CHN; q += nthreads) *reinterpret_cast<Chunk16*>(hbuf + q * CHN) = zero;
@@ -804,6 +833,25 @@ extern "C" int vitpe_fused_attention_fwd(int dtype, const void* xn, const void* 
   if (B == 0) return 0;
   AttnArgs a{};
   a.xn = xn; a.wqkv = wqkv; a.out = out; a.cos = cos; a.sin = sin; a.table = table; a.coeff = coeff;
+  a.B = B; a.N = N; a.mode = mode; a.grid = grid; a.degree = degree; a.coeff_per_head = coeff_per_head;
+  a.scale = 1.0f / sqrtf((float)HD);
+  return dispatch_attn(false, dtype, D, HD, a, stream);
+}
+
+// Same as vitpe_fused_attention_fwd with the preceding LayerNorm fused into the token staging:
+// x holds the RAW tokens, mean/rstd their row statistics (e.g. from vitpe_linear's stats output);
+// xn_out (nullable) receives LayerNorm(x) for the backward pass.
+extern "C" int vitpe_fused_attention_fwd_ln(int dtype, const void* x, const float* gamma, const float* beta,
+                                            const float* mean, const float* rstd, void* xn_out, const void* wqkv,
+                                            void* out, int B, int N, int D, int HD, int mode, const float* cos,
+                                            const float* sin, const float* table, const float* coeff, int grid,
+                                            int degree, int coeff_per_head, hipStream_t stream) {
+  VITPE_REQUIRE(x && gamma && beta && mean && rstd && wqkv && out && B >= 0 && N >= 2);
+  VITPE_REQUIRE(check_pe(mode, cos, sin, table, coeff, N, grid, degree));
+  if (B == 0) return 0;
+  AttnArgs a{};
+  a.xn = x; a.wqkv = wqkv; a.out = out; a.cos = cos; a.sin = sin; a.table = table; a.coeff = coeff;
+  a.ln_gamma = gamma; a.ln_beta = beta; a.ln_mean = mean; a.ln_rstd = rstd; a.xn_out = xn_out;
   a.B = B; a.N = N; a.mode = mode; a.grid = grid; a.degree = degree; a.coeff_per_head = coeff_per_head;
   a.scale = 1.0f / sqrtf((float)HD);
   return dispatch_attn(false, dtype, D, HD, a, stream);

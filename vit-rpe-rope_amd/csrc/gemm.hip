@@ -12,7 +12,7 @@
 
 namespace vitpe {
 
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2, EPI_PATCH = 3, EPI_GELU_BWD = 4 };
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2, EPI_PATCH = 3, EPI_GELU_BWD = 4, EPI_LN_BWD = 5 };
 
 struct GemmNTArgs {
   const void* A;      // [M,K] T
@@ -221,10 +221,23 @@ struct GemmPanelArgs {
   int M, N, K;
   int panel_rows;     // rows per workgroup panel (<= 144)
   float eps;
+  // LNA (template): A is normalised on the way into LDS with these row statistics / parameters;
+  // xn_out (nullable) receives the normalised A.   EPI_LN_BWD: the tile is dxn = dLN-output; the epilogue
+  // turns it into dx = R + rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dxn*gamma, xhat = (X-mean)*rstd
+  // (X = ln_x, the LayerNorm INPUT rows) and accumulates dgamma / dbeta.
+  const float* ln_gamma;
+  const float* ln_beta;
+  const float* ln_mean;
+  const float* ln_rstd;
+  void* xn_out;
+  const void* ln_x;
+  float* dgamma;
+  float* dbeta;
 };
 
-template <typename T, int EPI, bool STATS>
+template <typename T, int EPI, bool STATS, bool LNA>
 __global__ __launch_bounds__(768) void gemm_panel_kernel(GemmPanelArgs a) {
+  constexpr bool ROWMAP = STATS || (EPI == EPI_LN_BWD);   // 32 lanes per output row in the epilogue
   constexpr int BM = 144, BN = 192, ROWB = 128;
   constexpr int BK = ROWB / (int)sizeof(T), CPS = BK / 32, CHN = CH<T>::n;
   constexpr int STAGE = (BM + BN) * ROWB;                 // 43008 B
@@ -261,7 +274,24 @@ __global__ __launch_bounds__(768) void gemm_panel_kernel(GemmPanelArgs a) {
       Chunk16 v = zero;
       if (q < NCH && kk < K) {
         if (row < BM) {
-          if (m0 + row < m_end) v = *reinterpret_cast<const Chunk16*>(A + (size_t)(m0 + row) * K + kk);
+          if (m0 + row < m_end) {
+            v = *reinterpret_cast<const Chunk16*>(A + (size_t)(m0 + row) * K + kk);
+            if (LNA) {
+              const float mean = a.ln_mean[m0 + row], rstd = a.ln_rstd[m0 + row];
+              float f[CHN];
+              chunk_to_f32<T>(v, f);
+#pragma unroll
+              for (int h4 = 0; h4 < CHN / 4; ++h4) {
+                const f32x4 gq = *reinterpret_cast<const f32x4*>(a.ln_gamma + kk + 4 * h4);
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(a.ln_beta + kk + 4 * h4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) f[4 * h4 + t] = (f[4 * h4 + t] - mean) * rstd * gq[t] + bq[t];
+              }
+              v = f32_to_chunk<T>(f);
+              if (a.xn_out != nullptr && st < nk)   // first column tile only
+                *reinterpret_cast<Chunk16*>(reinterpret_cast<T*>(a.xn_out) + (size_t)(m0 + row) * K + kk) = v;
+            }
+          }
         } else {
           v = *reinterpret_cast<const Chunk16*>(W + (size_t)(n0 + row - BM) * K + kk);
         }
@@ -325,10 +355,16 @@ __global__ __launch_bounds__(768) void gemm_panel_kernel(GemmPanelArgs a) {
   float* ep = reinterpret_cast<float*>(smem);
   auto epilogue = [&](int n0) {
     const float invN = 1.0f / (float)BN;
+    // EPI_LN_BWD (N == BN: this is the workgroup's only tile): column sums of this thread's 8 columns over
+    // its rows; they live only inside the epilogue so the K loop carries no extra registers
+    float lnacc_g[8], lnacc_b[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { lnacc_g[t] = 0.f; lnacc_b[t] = 0.f; }
     // coalesced phase: 48 rows x 24 pieces of 8 columns.  Dense mapping (piece q = tid + 768 i) by
     // default; with STATS every row gets 32 lanes (8 idle) so its statistics reduce with shuffles.
 #pragma unroll
-    for (int pass = 0; pass < 3; ++pass) {           // pass = the mt tile every wave parks (static index!)
+    for (int pass = 0; pass < 3; ++pass) {           // pass = the mt tile every wave parks (static index: a
+                                                     // runtime `pass` sends the accumulators to scratch, measured 2x)
       __syncthreads();                               // stage buffers / previous pass fully consumed
 #pragma unroll
       for (int nt = 0; nt < 3; ++nt)
@@ -337,9 +373,9 @@ __global__ __launch_bounds__(768) void gemm_panel_kernel(GemmPanelArgs a) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int qd = tid + 768 * i;
-        const int row = STATS ? (tid >> 5) + 24 * i : qd / 24;   // parked row: wave-row row/16, c = row%16
-        const int pc = STATS ? (tid & 31) : qd % 24;
-        const bool live = STATS ? (pc < 24) : (qd < 48 * 24);
+        const int row = ROWMAP ? (tid >> 5) + 24 * i : qd / 24;   // parked row: wave-row row/16, c = row%16
+        const int pc = ROWMAP ? (tid & 31) : qd % 24;
+        const bool live = ROWMAP ? (pc < 24) : (qd < 48 * 24);
         const int gm = m0 + (row >> 4) * 48 + 16 * pass + (row & 15), gn = n0 + pc * 8;
         const bool ok = live && (gm < m_end);
         float v[8];
@@ -351,7 +387,51 @@ __global__ __launch_bounds__(768) void gemm_panel_kernel(GemmPanelArgs a) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) { v[t] = x[t]; v[4 + t] = y[t]; }
         }
-        if (ok) {
+        if (EPI == EPI_LN_BWD) {
+          // v = dxn piece.  Row reductions over the 32 lanes of the row, then dx and the dgamma/dbeta sums.
+          const size_t off = (size_t)min(gm, m_end - 1) * N + gn;
+          float xh[8], gv[8], gmv[8];
+          float s1 = 0.f, s2 = 0.f;
+          const float mean = a.ln_mean[min(gm, m_end - 1)], rstd = a.ln_rstd[min(gm, m_end - 1)];
+          if (live) {
+            float xv[8];
+#pragma unroll
+            for (int h = 0; h < 8 / CHN; ++h)
+              chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(reinterpret_cast<const T*>(a.ln_x) + off + h * CHN), xv + h * CHN);
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.ln_gamma + gn);
+            const f32x4 g1 = *reinterpret_cast<const f32x4*>(a.ln_gamma + gn + 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { gmv[t] = g0[t]; gmv[4 + t] = g1[t]; }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+              // the gradient as the unfused path sees it: dxn rounded to T
+              v[t] = to_f32(from_f32<T>(v[t]));
+              xh[t] = (xv[t] - mean) * rstd;
+              gv[t] = v[t] * gmv[t];
+              s1 += gv[t];
+              s2 += gv[t] * xh[t];
+            }
+          }
+#pragma unroll
+          for (int o = 16; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+          s1 *= invN;
+          s2 *= invN;
+          if (ok) {
+            float rv[8], o8[8];
+#pragma unroll
+            for (int h = 0; h < 8 / CHN; ++h)
+              chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(reinterpret_cast<const T*>(a.R) + off + h * CHN), rv + h * CHN);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+              o8[t] = rstd * (gv[t] - s1 - xh[t] * s2) + rv[t];
+              lnacc_g[t] += v[t] * xh[t];
+              lnacc_b[t] += v[t];
+            }
+#pragma unroll
+            for (int h = 0; h < 8 / CHN; ++h)
+              *reinterpret_cast<Chunk16*>(C + off + h * CHN) = f32_to_chunk<T>(o8 + h * CHN);
+          }
+        } else if (ok) {
           if (EPI != EPI_GELU_BWD && a.bias != nullptr) {
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + gn);
             const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.bias + gn + 4);
@@ -410,6 +490,28 @@ __global__ __launch_bounds__(768) void gemm_panel_kernel(GemmPanelArgs a) {
       }
     }
     __syncthreads();                                 // parked tile consumed before the next slab is stored
+    if (EPI == EPI_LN_BWD) {
+      // thread (row-group tid>>5, piece pc = tid&31) holds sums for columns 8pc..8pc+7: reduce the 24 row
+      // groups through LDS (the stage buffers are idle), then one atomic per column and workgroup
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(smem);   // [24][2][192]
+      const int pc = tid & 31, grp = tid >> 5;
+      if (pc < 24) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          red[(grp * 2 + 0) * BN + pc * 8 + t] = lnacc_g[t];
+          red[(grp * 2 + 1) * BN + pc * 8 + t] = lnacc_b[t];
+        }
+      }
+      __syncthreads();
+      if (tid < 2 * BN) {
+        const int which = tid / BN, col = tid % BN;
+        float sres = 0.f;
+#pragma unroll
+        for (int k = 0; k < 24; ++k) sres += red[(k * 2 + which) * BN + col];
+        atomicAdd((which == 0 ? a.dgamma : a.dbeta) + col, sres);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -606,17 +708,26 @@ static int launch_gemm_panel(int epi, GemmPanelArgs a, hipStream_t s) {
   dim3 grid(npanels), block(768);
   if (a.mean_out != nullptr) {
     switch (epi) {
-      case EPI_BIAS: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS, true>), grid, block, 0, s, a); break;
-      case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS_RESID, true>), grid, block, 0, s, a); break;
+      case EPI_BIAS: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS, true, false>), grid, block, 0, s, a); break;
+      case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS_RESID, true, false>), grid, block, 0, s, a); break;
+      default: return (int)hipErrorInvalidValue;
+    }
+    VITPE_CHECK_LAUNCH();
+  }
+  if (a.ln_gamma != nullptr && epi != EPI_LN_BWD) {   // LayerNorm fused into the A-operand staging
+    switch (epi) {
+      case EPI_BIAS: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS, false, true>), grid, block, 0, s, a); break;
+      case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS_GELU, false, true>), grid, block, 0, s, a); break;
       default: return (int)hipErrorInvalidValue;
     }
     VITPE_CHECK_LAUNCH();
   }
   switch (epi) {
-    case EPI_BIAS: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS, false>), grid, block, 0, s, a); break;
-    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS_GELU, false>), grid, block, 0, s, a); break;
-    case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS_RESID, false>), grid, block, 0, s, a); break;
-    case EPI_GELU_BWD: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_GELU_BWD, false>), grid, block, 0, s, a); break;
+    case EPI_BIAS: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS, false, false>), grid, block, 0, s, a); break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS_GELU, false, false>), grid, block, 0, s, a); break;
+    case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS_RESID, false, false>), grid, block, 0, s, a); break;
+    case EPI_GELU_BWD: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_GELU_BWD, false, false>), grid, block, 0, s, a); break;
+    case EPI_LN_BWD: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_LN_BWD, false, false>), grid, block, 0, s, a); break;
     default: return (int)hipErrorInvalidValue;
   }
   VITPE_CHECK_LAUNCH();
@@ -638,8 +749,41 @@ extern "C" int vitpe_linear(int dtype, int epi, const void* A, const void* W, vo
     VITPE_REQUIRE(mean_out == nullptr);
     return vitpe_gemm_nt(dtype, epi, A, W, C, bias, R, U, nullptr, nullptr, M, N, K, 0, 0, stream);
   }
-  GemmPanelArgs a{A, W, C, bias, R, U, mean_out, rstd_out, M, N, K, 0, eps};
+  GemmPanelArgs a{};
+  a.A = A; a.W = W; a.C = C; a.bias = bias; a.R = R; a.U = U; a.mean_out = mean_out; a.rstd_out = rstd_out;
+  a.M = M; a.N = N; a.K = K; a.eps = eps;
   return dtype == 1 ? launch_gemm_panel<bf16>(epi, a, stream) : launch_gemm_panel<float>(epi, a, stream);
+}
+
+// fc1-style linear with the preceding LayerNorm fused into the A staging (vit.py:116,124):
+// C = epi(LN(X) W^T), X raw [M,K], mean/rstd its row statistics; xn_out (nullable) receives LN(X).
+// epi in {EPI_BIAS, EPI_BIAS_GELU}; N % 192 == 0.
+extern "C" int vitpe_linear_ln(int dtype, int epi, const void* X, const float* gamma, const float* beta,
+                               const float* mean, const float* rstd, void* xn_out, const void* W, void* C,
+                               const float* bias, void* U, int M, int N, int K, hipStream_t stream) {
+  VITPE_REQUIRE(X && gamma && beta && mean && rstd && W && C && M >= 0 && (dtype == 0 || dtype == 1));
+  VITPE_REQUIRE((epi == EPI_BIAS || epi == EPI_BIAS_GELU) && N % 192 == 0 && K % (dtype == 1 ? 8 : 4) == 0);
+  if (epi == EPI_BIAS_GELU) VITPE_REQUIRE(U != nullptr);
+  if (M == 0) return 0;
+  GemmPanelArgs a{};
+  a.A = X; a.W = W; a.C = C; a.bias = bias; a.U = U; a.M = M; a.N = N; a.K = K;
+  a.ln_gamma = gamma; a.ln_beta = beta; a.ln_mean = mean; a.ln_rstd = rstd; a.xn_out = xn_out;
+  return dtype == 1 ? launch_gemm_panel<bf16>(epi, a, stream) : launch_gemm_panel<float>(epi, a, stream);
+}
+
+// data-gradient GEMM with the LayerNorm backward fused into its epilogue (N == 192 == LayerNorm width):
+// dx = dres + LN'(dY Wt^T) for the LayerNorm whose input rows are x (statistics mean/rstd, weight gamma);
+// dgamma / dbeta accumulated (fp32 atomics, one per column and workgroup).
+extern "C" int vitpe_linear_lnbwd(int dtype, const void* dY, const void* Wt, void* dx, const void* x, const float* mean,
+                                  const float* rstd, const float* gamma, const void* dres, float* dgamma, float* dbeta,
+                                  int M, int K, hipStream_t stream) {
+  VITPE_REQUIRE(dY && Wt && dx && x && mean && rstd && gamma && dres && dgamma && dbeta && M >= 0);
+  VITPE_REQUIRE((dtype == 0 || dtype == 1) && K % (dtype == 1 ? 8 : 4) == 0);
+  if (M == 0) return 0;
+  GemmPanelArgs a{};
+  a.A = dY; a.W = Wt; a.C = dx; a.R = dres; a.M = M; a.N = 192; a.K = K;
+  a.ln_gamma = gamma; a.ln_mean = mean; a.ln_rstd = rstd; a.ln_x = x; a.dgamma = dgamma; a.dbeta = dbeta;
+  return dtype == 1 ? launch_gemm_panel<bf16>(EPI_LN_BWD, a, stream) : launch_gemm_panel<float>(EPI_LN_BWD, a, stream);
 }
 
 template <typename T>

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 #pragma unroll
         for (int t = 0; t < CHN; ++t)
           o[t] = (v[i][t] - mean) * rstd * gamma[ch * CHN + t] + beta[ch * CHN + t];
-        *reinterpret_cast<Chunk16*>(y + (size_t)row * D + ch * CHN) = f32_to_chunk<T>(o);
+        if (y != nullptr) *reinterpret_cast<Chunk16*>(y + (size_t)row * D + ch * CHN) = f32_to_chunk<T>(o);
       }
     }
     if (lane == 0) {
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void ln_fwd32_kernel(const bf16* __restrict__ 
       float o8[8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) o8[t] = (v[t] - mean) * rstd * gm[t] + bt[t];
-      *reinterpret_cast<Chunk16*>(y + (size_t)row * D + lane * 8) = f32_to_chunk<bf16>(o8);
+      if (y != nullptr) *reinterpret_cast<Chunk16*>(y + (size_t)row * D + lane * 8) = f32_to_chunk<bf16>(o8);
     }
     if (lane == 0) {
       if (mean_out) mean_out[row] = mean;
@@ -189,12 +189,14 @@ __global__ __launch_bounds__(256) void ln_fwd32_kernel(const bf16* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(256) void ln_bwd32_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+// 1024 threads = 32 half-waves per block: one block per CU keeps 64 rows in flight while the
+// dgamma/dbeta atomics stay at one per column and block
+__global__ __launch_bounds__(1024) void ln_bwd32_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                        const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                        const float* __restrict__ gamma, const bf16* __restrict__ dres,
                                                        bf16* __restrict__ dx, float* __restrict__ dgamma,
                                                        float* __restrict__ dbeta, int M, int D) {
-  __shared__ float sred[8][2][256];
+  __shared__ float sred[32][2][256];
   const int lane = threadIdx.x & 31, sub = threadIdx.x >> 5;
   const int nch = D / 8;
   const float invD = 1.0f / (float)D;
@@ -202,44 +204,64 @@ __global__ __launch_bounds__(256) void ln_bwd32_kernel(const bf16* __restrict__ 
   float gm[8], ag[8], ab[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) { gm[t] = act ? gamma[lane * 8 + t] : 0.f; ag[t] = 0.f; ab[t] = 0.f; }
-  for (int row = blockIdx.x * 8 + sub; row < M; row += gridDim.x * 8) {
-    float xh[8], g8[8], rv[8];
-    float s1 = 0.f, s2 = 0.f;
-    const float mean = mean_in[row], rstd = rstd_in[row];
-    if (act) {
-      float xv[8], dv[8];
-      chunk_to_f32<bf16>(*reinterpret_cast<const Chunk16*>(x + (size_t)row * D + lane * 8), xv);
-      chunk_to_f32<bf16>(*reinterpret_cast<const Chunk16*>(dy + (size_t)row * D + lane * 8), dv);
-      if (dres != nullptr) chunk_to_f32<bf16>(*reinterpret_cast<const Chunk16*>(dres + (size_t)row * D + lane * 8), rv);
+  // two rows per half-wave in flight: all loads of both rows are issued before the first reduction
+  const int stride = gridDim.x * 32;
+  for (int row0 = blockIdx.x * 32 + sub; row0 < M; row0 += 2 * stride) {
+    float xh[2][8], g8[2][8], rv[2][8], dv[2][8];
+    float mean[2], rstd[2], s1[2], s2[2];
+    bool ok[2];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        xh[t] = (xv[t] - mean) * rstd;
-        g8[t] = dv[t] * gm[t];
-        s1 += g8[t];
-        s2 += g8[t] * xh[t];
-        ag[t] += dv[t] * xh[t];
-        ab[t] += dv[t];
+    for (int k = 0; k < 2; ++k) {
+      const int row = row0 + k * stride;
+      ok[k] = act && row < M;
+      mean[k] = rstd[k] = 0.f;
+      if (row < M) { mean[k] = mean_in[row]; rstd[k] = rstd_in[row]; }
+      if (ok[k]) {
+        chunk_to_f32<bf16>(*reinterpret_cast<const Chunk16*>(x + (size_t)row * D + lane * 8), xh[k]);
+        chunk_to_f32<bf16>(*reinterpret_cast<const Chunk16*>(dy + (size_t)row * D + lane * 8), dv[k]);
+        if (dres != nullptr) chunk_to_f32<bf16>(*reinterpret_cast<const Chunk16*>(dres + (size_t)row * D + lane * 8), rv[k]);
       }
     }
 #pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-    s1 *= invD;
-    s2 *= invD;
-    if (act) {
-      float o8[8];
+    for (int k = 0; k < 2; ++k) {
+      s1[k] = s2[k] = 0.f;
+      if (ok[k]) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) o8[t] = rstd * (g8[t] - s1 - xh[t] * s2) + (dres != nullptr ? rv[t] : 0.f);
-      *reinterpret_cast<Chunk16*>(dx + (size_t)row * D + lane * 8) = f32_to_chunk<bf16>(o8);
+        for (int t = 0; t < 8; ++t) {
+          xh[k][t] = (xh[k][t] - mean[k]) * rstd[k];
+          g8[k][t] = dv[k][t] * gm[t];
+          s1[k] += g8[k][t];
+          s2[k] += g8[k][t] * xh[k][t];
+          ag[t] += dv[k][t] * xh[k][t];
+          ab[t] += dv[k][t];
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) {
+      s1[0] += __shfl_xor(s1[0], o, 64); s2[0] += __shfl_xor(s2[0], o, 64);
+      s1[1] += __shfl_xor(s1[1], o, 64); s2[1] += __shfl_xor(s2[1], o, 64);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (ok[k]) {
+        const int row = row0 + k * stride;
+        const float m1 = s1[k] * invD, m2 = s2[k] * invD;
+        float o8[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) o8[t] = rstd[k] * (g8[k][t] - m1 - xh[k][t] * m2) + (dres != nullptr ? rv[k][t] : 0.f);
+        *reinterpret_cast<Chunk16*>(dx + (size_t)row * D + lane * 8) = f32_to_chunk<bf16>(o8);
+      }
     }
   }
 #pragma unroll
   for (int t = 0; t < 8; ++t) { sred[sub][0][lane * 8 + t] = ag[t]; sred[sub][1][lane * 8 + t] = ab[t]; }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * D; i += 256) {
+  for (int i = threadIdx.x; i < 2 * D; i += 1024) {
     const int which = i / D, d = i % D;
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += sred[k][which][d];
+    for (int k = 0; k < 32; ++k) t += sred[k][which][d];
     atomicAdd((which == 0 ? dgamma : dbeta) + d, t);
   }
 }
@@ -285,7 +307,8 @@ static inline bool ln_dims_ok(int dtype, int D) {
 
 extern "C" int vitpe_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y,
                                    float* mean, float* rstd, int M, int D, float eps, hipStream_t stream) {
-  VITPE_REQUIRE(x && gamma && beta && y && M >= 0);
+  VITPE_REQUIRE(x && gamma && beta && M >= 0);   // y == NULL: statistics only
+  VITPE_REQUIRE((y != nullptr) || (mean && rstd));
   VITPE_REQUIRE((dtype == 0 || dtype == 1) && ln_dims_ok(dtype, D));
   if (M == 0) return 0;
   const int blocks = min((M + 3) / 4, 2048);
@@ -316,7 +339,7 @@ extern "C" int vitpe_layernorm_bwd(int dtype, const void* dy, const void* x, con
   const int blocks = vitpe_layernorm_bwd_blocks(M);
   const size_t shm = (size_t)4 * 2 * D * sizeof(float);
   if (dtype == 1 && D <= 256) {
-    hipLaunchKernelGGL(ln_bwd32_kernel, dim3(min((M + 7) / 8, 512)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)x,
+    hipLaunchKernelGGL(ln_bwd32_kernel, dim3(min((M + 63) / 64, 256)), dim3(1024), 0, stream, (const bf16*)dy, (const bf16*)x,
                        mean, rstd, gamma, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, M, D);
     VITPE_CHECK_LAUNCH();
   }

@@ -33,7 +33,7 @@ ALIGN = 8  # elements: keeps every parameter 32-B (fp32) / 16-B (bf16 shadow) al
 
 class TrainEngine:
     def __init__(self, model: VisionTransformer, batch_size: int, compute_dtype=torch.bfloat16, lr=1e-3,
-                 weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8, process_group=None, use_graph=True):
+                 weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8, process_group=None, use_graph=True, fuse_ln=None):
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise L.VitpeError("TrainEngine needs the model on the HIP device (no CPU path)")
@@ -42,6 +42,12 @@ class TrainEngine:
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.use_graph = use_graph
         m = model
+        # LayerNorm fused into the neighbouring kernels (needs the 192-wide panel GEMM).  fuse_ln: None/"fwd"
+        # = forward only (default: the fused LayerNorm-backward epilogue spills and is not faster than the
+        # stand-alone kernel yet), True = forward and backward, False = stand-alone LayerNorm kernels.
+        ok = m.embed_dim == 192
+        self.fuse_ln = ok and fuse_ln is not False
+        self.fuse_ln_bwd = ok and fuse_ln is True
         self.D, self.H, self.Lyr = m.embed_dim, m.num_heads, len(m.blocks)
         self.p = m.patch_size
         self.C = m.patch_embed.weight.shape[1]
@@ -192,8 +198,28 @@ class TrainEngine:
                            mdl.cls_token.data.view(-1), ape, B, self.P, out=self.x[0])
         if isinstance(mdl.pos_embed, RoPEMixed):  # learnable frequencies: tables follow the parameters
             K.rope_mixed_tables(mdl.pos_embed.freqs.data, self.grid, self.pe.cos, self.pe.sin)
+        if self.fuse_ln:
+            b0 = mdl.blocks[0]
+            K.layernorm_fwd(self.x[0], b0.norm1.weight.data, b0.norm1.bias.data, b0.norm1.eps, mean=self.act[0]["m1"],
+                            rstd=self.act[0]["r1"], stats_only=True)
         for l, blk in enumerate(mdl.blocks):
             a, xin = self.act[l], self.x[l]
+            if self.fuse_ln:
+                # LN1 inside the attention kernel's token staging; LN2 inside fc1's operand staging; their
+                # statistics come out of the producing GEMM's epilogue (proj / previous fc2)
+                K.fused_attention_fwd(xin, self.Pk(blk.attn.qkv.weight), self.H, self.pe, out=a["a"],
+                                      ln=(blk.norm1.weight.data, blk.norm1.bias.data, a["m1"], a["r1"]), xn_out=a["xn1"])
+                K.linear(a["a"].view(M, D), self.Sh(blk.attn.proj.weight), blk.attn.proj.bias.data,
+                         epi=L.EPI_BIAS_RESID, resid=xin.view(M, D), out=a["xmid"].view(M, D), stats=(a["m2"], a["r2"]),
+                         eps=blk.norm2.eps)
+                K.linear_ln(a["xmid"].view(M, D), blk.norm2.weight.data, blk.norm2.bias.data, a["m2"], a["r2"],
+                            self.Sh(blk.mlp.fc1.weight), blk.mlp.fc1.bias.data, epi=L.EPI_BIAS_GELU, u=a["u"], out=a["h"],
+                            xn_out=a["xn2"].view(M, D))
+                nxt = (self.act[l + 1]["m1"], self.act[l + 1]["r1"]) if l + 1 < self.Lyr else None
+                K.linear(a["h"], self.Sh(blk.mlp.fc2.weight), blk.mlp.fc2.bias.data, epi=L.EPI_BIAS_RESID,
+                         resid=a["xmid"].view(M, D), out=self.x[l + 1].view(M, D), stats=nxt,
+                         eps=mdl.blocks[min(l + 1, self.Lyr - 1)].norm1.eps)
+                continue
             K.layernorm_fwd(xin, blk.norm1.weight.data, blk.norm1.bias.data, blk.norm1.eps, out=a["xn1"],
                             mean=a["m1"], rstd=a["r1"])
             K.fused_attention_fwd(a["xn1"], self.Pk(blk.attn.qkv.weight), self.H, self.pe, out=a["a"])
@@ -224,10 +250,16 @@ class TrainEngine:
             dy = cur.view(M, D)
             K.linear(dy, self.St(blk.mlp.fc2.weight), None, epi=L.EPI_GELU_BWD, u=a["u"], out=self.du)
             K.gemm_tn(dy, a["h"], G(blk.mlp.fc2.weight), G(blk.mlp.fc2.bias))
-            K.linear(self.du, self.St(blk.mlp.fc1.weight), None, out=self.dtmp.view(M, D))
+            if self.fuse_ln_bwd:   # data gradient of fc1 + LayerNorm2 backward + residual add in one kernel
+                K.linear_lnbwd(self.du, self.St(blk.mlp.fc1.weight), a["xmid"].view(M, D), a["m2"], a["r2"],
+                               blk.norm2.weight.data, cur.view(M, D), G(blk.norm2.weight), G(blk.norm2.bias),
+                               out=other.view(M, D))
+            else:
+                K.linear(self.du, self.St(blk.mlp.fc1.weight), None, out=self.dtmp.view(M, D))
             K.gemm_tn(self.du, a["xn2"].view(M, D), G(blk.mlp.fc1.weight), G(blk.mlp.fc1.bias))
-            K.layernorm_bwd(self.dtmp, a["xmid"], a["m2"], a["r2"], blk.norm2.weight.data, G(blk.norm2.weight),
-                            G(blk.norm2.bias), dres=cur, out=other, workspace=self.ln_ws)
+            if not self.fuse_ln_bwd:
+                K.layernorm_bwd(self.dtmp, a["xmid"], a["m2"], a["r2"], blk.norm2.weight.data, G(blk.norm2.weight),
+                                G(blk.norm2.bias), dres=cur, out=other, workspace=self.ln_ws)
             cur, other = other, cur
             # ---- attention branch: xmid = x_in + proj(attn(LN1(x_in)))
             dy = cur.view(M, D)
@@ -235,10 +267,16 @@ class TrainEngine:
             K.gemm_tn(dy, a["a"].view(M, D), G(blk.attn.proj.weight), G(blk.attn.proj.bias))
             K.fused_attention_bwd(a["xn1"], self.Pk(blk.attn.qkv.weight), self.dtmp, self.H, self.pe,
                                   out=self.dqkv, **self.pe_grads)
-            K.linear(self.dqkv.view(M, 3 * D), self.St(blk.attn.qkv.weight), None, out=self.dtmp.view(M, D))
+            if self.fuse_ln_bwd:   # data gradient of qkv + LayerNorm1 backward + residual add in one kernel
+                K.linear_lnbwd(self.dqkv.view(M, 3 * D), self.St(blk.attn.qkv.weight), self.x[l].view(M, D), a["m1"],
+                               a["r1"], blk.norm1.weight.data, cur.view(M, D), G(blk.norm1.weight), G(blk.norm1.bias),
+                               out=other.view(M, D))
+            else:
+                K.linear(self.dqkv.view(M, 3 * D), self.St(blk.attn.qkv.weight), None, out=self.dtmp.view(M, D))
             K.gemm_tn(self.dqkv.view(M, 3 * D), a["xn1"].view(M, D), G(blk.attn.qkv.weight), None)
-            K.layernorm_bwd(self.dtmp, self.x[l], a["m1"], a["r1"], blk.norm1.weight.data, G(blk.norm1.weight),
-                            G(blk.norm1.bias), dres=cur, out=other, workspace=self.ln_ws)
+            if not self.fuse_ln_bwd:
+                K.layernorm_bwd(self.dtmp, self.x[l], a["m1"], a["r1"], blk.norm1.weight.data, G(blk.norm1.weight),
+                                G(blk.norm1.bias), dres=cur, out=other, workspace=self.ln_ws)
             cur, other = other, cur
         dape = None
         if isinstance(mdl.pos_embed, AbsolutePositionalEncoding):

@@ -55,6 +55,31 @@ def linear(a, w, bias=None, epi=L.EPI_BIAS, resid=None, u=None, out=None, stats=
     return (c, u) if epi == L.EPI_BIAS_GELU else c
 
 
+def linear_ln(x, gamma, beta, mean, rstd, w, bias=None, epi=L.EPI_BIAS, u=None, out=None, xn_out=None):
+    """epi(LayerNorm(x) W^T) with the LayerNorm applied while staging x (row statistics given)."""
+    require_device(x, gamma, beta, mean, rstd, w, bias, u, out, xn_out)
+    M, K = x.shape
+    N = w.shape[0]
+    c = out if out is not None else torch.empty((M, N), dtype=x.dtype, device=x.device)
+    if epi == L.EPI_BIAS_GELU and u is None:
+        u = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    check(lib().vitpe_linear_ln(dtype_code(x.dtype), epi, ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
+                                ptr(xn_out), ptr(w), ptr(c), ptr(bias), ptr(u), M, N, K, stream_ptr()), "vitpe_linear_ln")
+    return (c, u) if epi == L.EPI_BIAS_GELU else c
+
+
+def linear_lnbwd(dy, wt, x, mean, rstd, gamma, dres, dgamma, dbeta, out=None):
+    """dx = dres + LayerNorm'(dy wt^T) (LayerNorm input rows x); dgamma/dbeta accumulated."""
+    require_device(dy, wt, x, mean, rstd, gamma, dres, dgamma, dbeta, out)
+    M, K = dy.shape
+    assert wt.shape == (192, K) and x.shape[-1] == 192
+    dx = out if out is not None else torch.empty((M, 192), dtype=dy.dtype, device=dy.device)
+    check(lib().vitpe_linear_lnbwd(dtype_code(dy.dtype), ptr(dy), ptr(wt), ptr(dx), ptr(x), ptr(mean), ptr(rstd),
+                                   ptr(gamma), ptr(dres), ptr(dgamma), ptr(dbeta), M, K, stream_ptr()),
+          "vitpe_linear_lnbwd")
+    return dx
+
+
 def patch_embed_gemm(patches, w, bias, cls, ape, B, P, out=None):
     """tokens[B,P+1,N] from unfolded patches [B*P,K] (vit.py:248-258)."""
     require_device(patches, w, bias, cls, ape, out)
@@ -88,12 +113,12 @@ def gemm_tn(dy, x, dw, dbias=None, splits=None):
 
 
 # ---- LayerNorm ------------------------------------------------------------------------------
-def layernorm_fwd(x, gamma, beta, eps=1e-5, out=None, mean=None, rstd=None):
+def layernorm_fwd(x, gamma, beta, eps=1e-5, out=None, mean=None, rstd=None, stats_only=False):
     require_device(x, gamma, beta, out)
     D = x.shape[-1]
     M = x.numel() // D
     _f32(gamma, "gamma"), _f32(beta, "beta")
-    y = out if out is not None else torch.empty_like(x)
+    y = None if stats_only else (out if out is not None else torch.empty_like(x))
     mean = mean if mean is not None else torch.empty(M, dtype=torch.float32, device=x.device)
     rstd = rstd if rstd is not None else torch.empty(M, dtype=torch.float32, device=x.device)
     check(lib().vitpe_layernorm_fwd(dtype_code(x.dtype), ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd),
@@ -148,13 +173,22 @@ def pack_qkv_weights(wqkv_f32, dtype, num_heads, out=None):
     return o
 
 
-def fused_attention_fwd(xn, wqkv, num_heads, pe: PETables, out=None):
-    """wqkv: PACKED weights (pack_qkv_weights)."""
-    require_device(xn, wqkv, pe.cos, pe.sin, pe.table, pe.coeff, out)
+def fused_attention_fwd(xn, wqkv, num_heads, pe: PETables, out=None, ln=None, xn_out=None):
+    """wqkv: PACKED weights (pack_qkv_weights).  ln=(gamma, beta, mean, rstd): `xn` holds the RAW tokens and
+    the LayerNorm is applied while staging them (xn_out then receives LayerNorm(x))."""
+    require_device(xn, wqkv, pe.cos, pe.sin, pe.table, pe.coeff, out, xn_out)
     B, N, D = xn.shape
     HD = D // num_heads
     assert wqkv.numel() == 3 * D * D and wqkv.dtype == xn.dtype
     o = out if out is not None else torch.empty_like(xn)
+    if ln is not None:
+        require_device(*ln)
+        check(lib().vitpe_fused_attention_fwd_ln(dtype_code(xn.dtype), ptr(xn), ptr(ln[0]), ptr(ln[1]), ptr(ln[2]),
+                                                 ptr(ln[3]), ptr(xn_out), ptr(wqkv), ptr(o), B, N, D, HD, pe.code,
+                                                 ptr(pe.cos), ptr(pe.sin), ptr(pe.table), ptr(pe.coeff), pe.grid,
+                                                 pe.degree, int(pe.coeff_per_head), stream_ptr()),
+              "vitpe_fused_attention_fwd_ln")
+        return o
     check(lib().vitpe_fused_attention_fwd(dtype_code(xn.dtype), ptr(xn), ptr(wqkv), ptr(o), B, N, D, HD, pe.code,
                                           ptr(pe.cos), ptr(pe.sin), ptr(pe.table), ptr(pe.coeff), pe.grid,
                                           pe.degree, int(pe.coeff_per_head), stream_ptr()),
