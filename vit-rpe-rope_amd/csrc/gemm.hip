@@ -572,9 +572,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
   const int wn = wave >> 1, wk = wave & 1;
-  const int n0 = blockIdx.x * TN, k0 = blockIdx.y * TK;
   const int M = a.M, N = a.N, K = a.K;
-  const int mbeg = blockIdx.z * a.rows_per_split;
+  // 1-D grid, XCD-local order: every (n,k) tile of one token slice lands on the same XCD back to back, so
+  // the slice's dY / X rows are fetched into that L2 once and re-read from there by the other tiles
+  const int ntn = (N + TN - 1) / TN, ntk = (K + TK - 1) / TK, ntile = ntn * ntk;
+  int t;
+  {
+    const int total = (int)gridDim.x, id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int q = total >> 3, r = total & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int zslice = t / ntile, tile = t % ntile;
+  const int n0 = (tile % ntn) * TN, k0 = (tile / ntn) * TK;
+  const int mbeg = zslice * a.rows_per_split;
   const int mend = min(M, mbeg + a.rows_per_split);
   const T* __restrict__ dY = reinterpret_cast<const T*>(a.dY);
   const T* __restrict__ X = reinterpret_cast<const T*>(a.X);
@@ -585,7 +595,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs a) {
 #pragma unroll
     for (int j = 0; j < KT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-  const bool do_bias = (a.dbias != nullptr) && (a.bias_from_x ? blockIdx.x == 0 : blockIdx.y == 0);
+  const bool do_bias = (a.dbias != nullptr) && (a.bias_from_x ? n0 == 0 : k0 == 0);
   const Chunk16 zero = {0u, 0u, 0u, 0u};
 
   Chunk16 ry[YIT], rx[XIT];
@@ -796,13 +806,13 @@ static int launch_gemm_tn(GemmTNArgs a, int splits, hipStream_t s) {
   dim3 block(256);
   if (false && a.K % 192 == 0) {  // 128x192 tiles: fewer panel re-reads but LDS-read bound on the transposed
                                    // fragment reads (measured 15 % slower than 128x64) -- kept for the redesign
-    dim3 grid((a.N + 127) / 128, a.K / 192, nz);
+    dim3 grid(((a.N + 127) / 128) * (a.K / 192) * nz);
     hipLaunchKernelGGL((gemm_tn_kernel<T, 192>), grid, block, 0, s, a);
   } else if (a.K % 128 == 0 || a.K > 192) {
-    dim3 grid((a.N + 127) / 128, (a.K + 127) / 128, nz);
+    dim3 grid(((a.N + 127) / 128) * ((a.K + 127) / 128) * nz);
     hipLaunchKernelGGL((gemm_tn_kernel<T, 128>), grid, block, 0, s, a);
   } else {
-    dim3 grid((a.N + 127) / 128, (a.K + 63) / 64, nz);
+    dim3 grid(((a.N + 127) / 128) * ((a.K + 63) / 64) * nz);
     hipLaunchKernelGGL((gemm_tn_kernel<T, 64>), grid, block, 0, s, a);
   }
   VITPE_CHECK_LAUNCH();
