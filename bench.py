@@ -59,7 +59,7 @@ def time_attention_kernel(eng, iters=100):
     torch.cuda.synchronize()
     fwd_ms = e0.elapsed_time(e1) / iters
     callb = lambda: K.fused_attention_bwd(a["xn1"], eng.Pk(blk.attn.qkv.weight), eng.dtmp, eng.H, eng.pe,  # noqa: E731
-                                          out=eng.dqkv, **eng.pe_grads)
+                                          out=eng.dqkv_l[0], **eng.pe_grads)
     for _ in range(5):
         callb()
     torch.cuda.synchronize()
@@ -77,6 +77,8 @@ def cpu_baseline(pos_encoding, steps=20, warmup=2, bs=128):
     """The CPU oracle's train step (fp32 eager torch ops, same op sequence as the reference) on
     the host cores of this box.  Baseline only; bounded to ~10-30 s."""
     from oracle import vit_oracle as O
+    # one GPU's share of the host is 16 cores; torch's default (all 256 logical CPUs of the node) oversubscribes
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     cfg = O.VitConfig(pos_encoding=pos_encoding)
     params = O.init_params(cfg, seed=0)
     st = O.AdamWState()

@@ -166,9 +166,17 @@ class TrainEngine:
         self.metric_acc = torch.zeros(2, dtype=torch.float32, device=dev)  # [sum of mean losses, #correct]
         self.head_ws = (f(B, D), f(B, D), f(B))
         self.ws_dyn = f(B, D)
-        self.dxa, self.dxb, self.dtmp = e(B, N, D), e(B, N, D), e(B, N, D)
-        self.dqkv = e(B, N, 3 * D)
-        self.du = e(M, self.hid)
+        # Gradient tensors read by the weight-gradient GEMMs get per-layer buffers (dy = d x_out, dmid = d x_mid,
+        # du, dqkv): the weight gradients run on a side stream, and with private buffers the main chain never
+        # overwrites anything they may still be reading (288 GB of HBM: ~0.7 GB extra is free)
+        self.dtmp = e(B, N, D)
+        self.dx_out = [e(B, N, D) for _ in range(self.Lyr + 1)]   # [l] = gradient w.r.t. x[l]
+        self.dx_mid = [e(B, N, D) for _ in range(self.Lyr)]
+        self.du_l = [e(M, self.hid) for _ in range(self.Lyr)]
+        self.dqkv_l = [e(B, N, 3 * D) for _ in range(self.Lyr)]
+        self.dqkv, self.du = self.dqkv_l[0], self.du_l[0]          # (bench.py times the kernels on these)
+        self.side = torch.cuda.Stream(device=dev)
+        self.overlap_wgrad = __import__("os").environ.get("VITPE_OVERLAP_WGRAD", "0") == "1"
         self.dpatch = e(B * self.P, D)
         self.ln_ws = K.layernorm_bwd_workspace(M, D, dev)
         # positional-encoding operands of the fused attention kernels
@@ -238,51 +246,64 @@ class TrainEngine:
         K.cross_entropy(self.logits, self.labels, grad_scale=1.0 / self.B, dlogits=self.dlogits, out2=self.out2)
         self.metric_acc.add_(self.out2)
 
+    def _wgrad(self, after_event, fn):
+        """Run a weight-gradient GEMM on the side stream once `after_event` (its producer) has completed."""
+        if not self.overlap_wgrad:
+            fn()
+            return
+        self.side.wait_event(after_event)
+        with torch.cuda.stream(self.side):
+            fn()
+
     def _backward(self):
         mdl, B, N, D, M = self.model, self.B, self.N, self.D, self.M
         G = self.Gr
+        main = torch.cuda.current_stream()
+        ev = lambda: (lambda e: (e.record(main), e)[1])(torch.cuda.Event())  # noqa: E731
+        dxL = self.dx_out[self.Lyr]
         K.head_bwd(self.dlogits, mdl.head.weight.data, mdl.norm.weight.data, self.head_ws, self.T, N, G(mdl.head.weight),
-                   G(mdl.head.bias), G(mdl.norm.weight), G(mdl.norm.bias), dx=self.dxa, ws_dyn=self.ws_dyn)
-        cur, other = self.dxa, self.dxb
+                   G(mdl.head.bias), G(mdl.norm.weight), G(mdl.norm.bias), dx=dxL, ws_dyn=self.ws_dyn)
         for l in range(self.Lyr - 1, -1, -1):
             blk, a = mdl.blocks[l], self.act[l]
+            dy3, dmid3, du, dqkv = self.dx_out[l + 1], self.dx_mid[l], self.du_l[l], self.dqkv_l[l]
+            dy = dy3.view(M, D)
+            e_dy = ev()
             # ---- MLP branch: x_out = xmid + fc2(gelu(fc1(LN2(xmid))))
-            dy = cur.view(M, D)
-            K.linear(dy, self.St(blk.mlp.fc2.weight), None, epi=L.EPI_GELU_BWD, u=a["u"], out=self.du)
-            K.gemm_tn(dy, a["h"], G(blk.mlp.fc2.weight), G(blk.mlp.fc2.bias))
+            self._wgrad(e_dy, lambda: K.gemm_tn(dy, a["h"], G(blk.mlp.fc2.weight), G(blk.mlp.fc2.bias)))
+            K.linear(dy, self.St(blk.mlp.fc2.weight), None, epi=L.EPI_GELU_BWD, u=a["u"], out=du)
+            e_du = ev()
+            self._wgrad(e_du, lambda: K.gemm_tn(du, a["xn2"].view(M, D), G(blk.mlp.fc1.weight), G(blk.mlp.fc1.bias)))
             if self.fuse_ln_bwd:   # data gradient of fc1 + LayerNorm2 backward + residual add in one kernel
-                K.linear_lnbwd(self.du, self.St(blk.mlp.fc1.weight), a["xmid"].view(M, D), a["m2"], a["r2"],
-                               blk.norm2.weight.data, cur.view(M, D), G(blk.norm2.weight), G(blk.norm2.bias),
-                               out=other.view(M, D))
+                K.linear_lnbwd(du, self.St(blk.mlp.fc1.weight), a["xmid"].view(M, D), a["m2"], a["r2"],
+                               blk.norm2.weight.data, dy, G(blk.norm2.weight), G(blk.norm2.bias), out=dmid3.view(M, D))
             else:
-                K.linear(self.du, self.St(blk.mlp.fc1.weight), None, out=self.dtmp.view(M, D))
-            K.gemm_tn(self.du, a["xn2"].view(M, D), G(blk.mlp.fc1.weight), G(blk.mlp.fc1.bias))
-            if not self.fuse_ln_bwd:
+                K.linear(du, self.St(blk.mlp.fc1.weight), None, out=self.dtmp.view(M, D))
                 K.layernorm_bwd(self.dtmp, a["xmid"], a["m2"], a["r2"], blk.norm2.weight.data, G(blk.norm2.weight),
-                                G(blk.norm2.bias), dres=cur, out=other, workspace=self.ln_ws)
-            cur, other = other, cur
+                                G(blk.norm2.bias), dres=dy3, out=dmid3, workspace=self.ln_ws)
             # ---- attention branch: xmid = x_in + proj(attn(LN1(x_in)))
-            dy = cur.view(M, D)
-            K.linear(dy, self.St(blk.attn.proj.weight), None, out=self.dtmp.view(M, D))
-            K.gemm_tn(dy, a["a"].view(M, D), G(blk.attn.proj.weight), G(blk.attn.proj.bias))
+            dm = dmid3.view(M, D)
+            e_dm = ev()
+            self._wgrad(e_dm, lambda: K.gemm_tn(dm, a["a"].view(M, D), G(blk.attn.proj.weight), G(blk.attn.proj.bias)))
+            K.linear(dm, self.St(blk.attn.proj.weight), None, out=self.dtmp.view(M, D))
             K.fused_attention_bwd(a["xn1"], self.Pk(blk.attn.qkv.weight), self.dtmp, self.H, self.pe,
-                                  out=self.dqkv, **self.pe_grads)
+                                  out=dqkv, **self.pe_grads)
+            e_dq = ev()
+            self._wgrad(e_dq, lambda: K.gemm_tn(dqkv.view(M, 3 * D), a["xn1"].view(M, D), G(blk.attn.qkv.weight), None))
             if self.fuse_ln_bwd:   # data gradient of qkv + LayerNorm1 backward + residual add in one kernel
-                K.linear_lnbwd(self.dqkv.view(M, 3 * D), self.St(blk.attn.qkv.weight), self.x[l].view(M, D), a["m1"],
-                               a["r1"], blk.norm1.weight.data, cur.view(M, D), G(blk.norm1.weight), G(blk.norm1.bias),
-                               out=other.view(M, D))
+                K.linear_lnbwd(dqkv.view(M, 3 * D), self.St(blk.attn.qkv.weight), self.x[l].view(M, D), a["m1"],
+                               a["r1"], blk.norm1.weight.data, dm, G(blk.norm1.weight), G(blk.norm1.bias),
+                               out=self.dx_out[l].view(M, D))
             else:
-                K.linear(self.dqkv.view(M, 3 * D), self.St(blk.attn.qkv.weight), None, out=self.dtmp.view(M, D))
-            K.gemm_tn(self.dqkv.view(M, 3 * D), a["xn1"].view(M, D), G(blk.attn.qkv.weight), None)
-            if not self.fuse_ln_bwd:
+                K.linear(dqkv.view(M, 3 * D), self.St(blk.attn.qkv.weight), None, out=self.dtmp.view(M, D))
                 K.layernorm_bwd(self.dtmp, self.x[l], a["m1"], a["r1"], blk.norm1.weight.data, G(blk.norm1.weight),
-                                G(blk.norm1.bias), dres=cur, out=other, workspace=self.ln_ws)
-            cur, other = other, cur
+                                G(blk.norm1.bias), dres=dmid3, out=self.dx_out[l], workspace=self.ln_ws)
         dape = None
         if isinstance(mdl.pos_embed, AbsolutePositionalEncoding):
             dape = G(mdl.pos_embed.pos_embed)[0, :self.P]
-        K.embed_bwd(cur, G(mdl.cls_token).view(-1), dape, out=self.dpatch)
+        K.embed_bwd(self.dx_out[0], G(mdl.cls_token).view(-1), dape, out=self.dpatch)
         K.gemm_tn(self.dpatch, self.patches, G(mdl.patch_embed.weight).view(D, -1), G(mdl.patch_embed.bias))
+        if self.overlap_wgrad:
+            main.wait_stream(self.side)   # join: every gradient is complete before the all-reduce / optimizer
 
     def _optimizer(self):
         K.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.hp, shadow_bf16=self.flat_s,
