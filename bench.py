@@ -73,6 +73,16 @@ def time_attention_kernel(eng, iters=100):
     return fwd_ms, bwd_ms
 
 
+def committed_pmc():
+    """HBM traffic / MFMA-busy of the roofline kernel from the committed rocprofv3 --pmc passes
+    (tools/pmc_attn.py + tools/summarize_pmc.py -> profiles/r01_attn_fwd_pmc.json; same kernel, same shape)."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_attn_fwd_pmc.json")) as f:
+            return json.load(f)["attn_fwd_kernel"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(pos_encoding, steps=20, warmup=2, bs=128):
     """The CPU oracle's train step (fp32 eager torch ops, same op sequence as the reference) on
     the host cores of this box.  Baseline only; bounded to ~10-30 s."""
@@ -148,6 +158,7 @@ def main():
     if rank == 0:
         flops = ATTN_FWD_FLOP_PER_IMG_LAYER * args.batch
         achieved = flops / (fwd_ms * 1e-3) / 1e12
+        pmc = committed_pmc() if (args.batch == 512 and args.dtype == "bf16") else None
         line = {
             "metric": "train images/sec, CIFAR-10 ViT d=192 L=6 H=6",
             "value": round(world * args.batch * args.steps / elapsed, 1),
@@ -163,7 +174,12 @@ def main():
                        "final_loss_mean": round(loss / max(args.steps + args.warmup, 1), 4)},
             "roofline": {"kernel": "attn_fwd_kernel (fused QKV-project+RoPE+QK^T+softmax+AV)", "bound": "mfma",
                          "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": (pmc["hbm_bytes_per_launch"] if pmc else None),
+                         "traffic_source": ("profiles/r01_attn_fwd_pmc.json: (FETCH_SIZE*2 + WRITE_SIZE) KB, separate "
+                                            "rocprofv3 --pmc passes" if pmc else None),
+                         "mfma_pipe_busy_frac": (round(pmc["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 /
+                                                       (pmc["SQ_BUSY_CYCLES"] / 32), 3) if pmc else None),
                          "launch_ms": round(fwd_ms, 5),
                          "algorithmic_flop_per_launch": flops,
                          "algorithmic_bytes_per_launch": ATTN_FWD_BYTES_PER_IMG_LAYER * args.batch,
