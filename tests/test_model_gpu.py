@@ -222,14 +222,23 @@ def test_engine_bf16_full_model_close_to_fp32_oracle_and_learns():
         ref_logits = O.forward(cfg, params, images)
     eng = TrainEngine(model, 16, compute_dtype=torch.bfloat16, use_graph=True)
     eng.images.copy_(images.cuda()); eng.labels.copy_(labels.cuda())
-    assert rel_err(eng.forward_only(images.cuda()).cpu(), ref_logits) < 5e-2
+    err = rel_err(eng.forward_only(images.cuda()).cpu(), ref_logits)
+    assert err < 5e-2, f"bf16 logits rel err {err}"
+    # learning check on the reference's own (random) init: with the closed-form weights the 30-step endpoint
+    # is chaotic (fp32 atomics reorder sums at the 1e-7 level and Adam amplifies it; tools/determinism.py)
+    from models.vit import VisionTransformer
+    torch.manual_seed(0)
+    model = VisionTransformer(pos_encoding="rope-axial").cuda()
+    eng = TrainEngine(model, 16, compute_dtype=torch.bfloat16, use_graph=True)
+    eng.images.copy_(images.cuda()); eng.labels.copy_(labels.cuda())
     eng.step()
     first = eng.read_metrics()[0]
     for _ in range(30):
         eng.step()
     eng.read_metrics()
     eng.step()
-    assert eng.read_metrics()[0] < 0.9 * first
+    last = eng.read_metrics()[0]
+    assert last < 0.5 * first, f"loss {first} -> {last}"
 
 
 def test_ragged_batch_through_dropin_module():

@@ -62,7 +62,14 @@ class TrainEngine:
             raise L.VitpeError(f"fused attention kernel does not support N={self.N}, D={self.D}, hd={self.D // self.H}")
         self._build_flat(lr, weight_decay, betas, eps)
         self._build_buffers()
-        self.graph_fb = self.graph_opt = None
+        # gradient exchange in two buckets so the first overlaps the lower half of the backward pass:
+        # flat[bucket_off:] = layers split.. + final norm + head (complete after the "upper" backward),
+        # flat[:bucket_off] = class token, patch embed, PE parameters, layers 0..split-1
+        self.split_layer = max(1, self.Lyr // 2)
+        self.bucket_off = self._off[id(next(self.model.blocks[self.split_layer].parameters()))] \
+            if self.Lyr >= 2 else 0
+        self.overlap_comm = self.world > 1 and self.Lyr >= 2
+        self.graph_fb = self.graph_fb2 = self.graph_opt = None
         self.steps_done = 0
 
     # ---------------------------------------------------------------- parameters / shadows
@@ -255,15 +262,23 @@ class TrainEngine:
         with torch.cuda.stream(self.side):
             fn()
 
-    def _backward(self):
+    def _backward(self, part="all"):
+        """part: "all" | "upper" (head + layers L-1..split) | "lower" (layers split-1..0 + patch embed)."""
         mdl, B, N, D, M = self.model, self.B, self.N, self.D, self.M
         G = self.Gr
         main = torch.cuda.current_stream()
         ev = lambda: (lambda e: (e.record(main), e)[1])(torch.cuda.Event())  # noqa: E731
-        dxL = self.dx_out[self.Lyr]
-        K.head_bwd(self.dlogits, mdl.head.weight.data, mdl.norm.weight.data, self.head_ws, self.T, N, G(mdl.head.weight),
-                   G(mdl.head.bias), G(mdl.norm.weight), G(mdl.norm.bias), dx=dxL, ws_dyn=self.ws_dyn)
-        for l in range(self.Lyr - 1, -1, -1):
+        hi, lo = self.Lyr - 1, 0
+        if part == "upper":
+            lo = self.split_layer
+        elif part == "lower":
+            hi = self.split_layer - 1
+        if part != "lower":
+            dxL = self.dx_out[self.Lyr]
+            K.head_bwd(self.dlogits, mdl.head.weight.data, mdl.norm.weight.data, self.head_ws, self.T, N,
+                       G(mdl.head.weight), G(mdl.head.bias), G(mdl.norm.weight), G(mdl.norm.bias), dx=dxL,
+                       ws_dyn=self.ws_dyn)
+        for l in range(hi, lo - 1, -1):
             blk, a = mdl.blocks[l], self.act[l]
             dy3, dmid3, du, dqkv = self.dx_out[l + 1], self.dx_mid[l], self.du_l[l], self.dqkv_l[l]
             dy = dy3.view(M, D)
@@ -297,11 +312,12 @@ class TrainEngine:
                 K.linear(dqkv.view(M, 3 * D), self.St(blk.attn.qkv.weight), None, out=self.dtmp.view(M, D))
                 K.layernorm_bwd(self.dtmp, self.x[l], a["m1"], a["r1"], blk.norm1.weight.data, G(blk.norm1.weight),
                                 G(blk.norm1.bias), dres=dmid3, out=self.dx_out[l], workspace=self.ln_ws)
-        dape = None
-        if isinstance(mdl.pos_embed, AbsolutePositionalEncoding):
-            dape = G(mdl.pos_embed.pos_embed)[0, :self.P]
-        K.embed_bwd(self.dx_out[0], G(mdl.cls_token).view(-1), dape, out=self.dpatch)
-        K.gemm_tn(self.dpatch, self.patches, G(mdl.patch_embed.weight).view(D, -1), G(mdl.patch_embed.bias))
+        if part != "upper":
+            dape = None
+            if isinstance(mdl.pos_embed, AbsolutePositionalEncoding):
+                dape = G(mdl.pos_embed.pos_embed)[0, :self.P]
+            K.embed_bwd(self.dx_out[0], G(mdl.cls_token).view(-1), dape, out=self.dpatch)
+            K.gemm_tn(self.dpatch, self.patches, G(mdl.patch_embed.weight).view(D, -1), G(mdl.patch_embed.bias))
         if self.overlap_wgrad:
             main.wait_stream(self.side)   # join: every gradient is complete before the all-reduce / optimizer
 
@@ -336,20 +352,24 @@ class TrainEngine:
         self.flat_g.zero_()
         self.refresh_shadows()
         torch.cuda.synchronize()
+        # thread_local: a communicator watchdog thread touching the device must not invalidate the capture
         self.graph_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_fb):
-            self._forward(); self._loss(); self._backward()
+        with torch.cuda.graph(self.graph_fb, capture_error_mode="thread_local"):
+            self._forward(); self._loss()
             if self.world == 1:
-                self._optimizer()
+                self._backward(); self._optimizer()
+            elif self.overlap_comm:
+                self._backward("upper")
+            else:
+                self._backward()
         if self.world > 1:
+            if self.overlap_comm:
+                self.graph_fb2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_fb2, capture_error_mode="thread_local"):
+                    self._backward("lower")
             self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt):
+            with torch.cuda.graph(self.graph_opt, capture_error_mode="thread_local"):
                 self._optimizer()
-            # capture ran the optimizer kernels once: undo
-            for t, c in zip((self.flat_p, self.flat_m, self.flat_v, self.hp, self.metric_acc), snap):
-                t.copy_(c)
-            self.flat_g.zero_()
-            self.refresh_shadows()
         torch.cuda.synchronize()
 
     def step(self, images: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None):
@@ -366,7 +386,14 @@ class TrainEngine:
                 self.capture()
             self.graph_fb.replay()
             if self.world > 1:
-                self._allreduce()
+                if self.overlap_comm:
+                    # bucket 1 (upper layers + head) is exchanged while the lower layers' backward runs
+                    w1 = dist.all_reduce(self.flat_g[self.bucket_off:], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                    self.graph_fb2.replay()
+                    w2 = dist.all_reduce(self.flat_g[:self.bucket_off], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                    w1.wait(); w2.wait()
+                else:
+                    self._allreduce()
                 self.graph_opt.replay()
         else:
             self._forward(); self._loss(); self._backward(); self._allreduce(); self._optimizer()
