@@ -85,6 +85,24 @@ int vitpe_fused_attention_bwd(int dtype, const void* xn, const void* wqkv, const
                               int degree, int coeff_per_head, float* dtable, float* dcoeff,
                               float* dfreqs, vitpe_stream_t stream);
 
+/* ---- attention core on a qkv buffer (geometries the fused kernels do not cover) -----------
+ * Replaces models/vit.py:49-92 between `qkv = self.qkv(x)` and `self.proj`: head split, RoPE on
+ * q,k (rope_utils.py:85-101; class token not rotated), QK^T*hd^-0.5 + relative / polynomial bias
+ * (positional_encoding.py:82-95,127-171), softmax, @V, head merge.  One workgroup per (image, head).
+ *   qkv  [B,N,3*H*HD] T  output of the qkv Linear (vitpe_linear), columns [q|k|v] x heads x HD
+ *   out  [B,N,H*HD]   T  merged heads ; dqkv same layout as qkv
+ * PE operands and gradient accumulation as for vitpe_fused_attention_*.  Supported:
+ * vitpe_attention_core_supported() -- (HD=64, 193<=N<=208: 224x224 / patch 16) and (HD=32, 65<=N<=80);
+ * rope-mixed needs H <= 16.  Anything else returns hipErrorNotSupported.                         */
+int vitpe_attention_core_supported(int dtype, int N, int HD);
+int vitpe_attention_core_fwd(int dtype, const void* qkv, void* out, int B, int N, int H, int HD, int mode,
+                             const float* cos, const float* sin, const float* table, const float* coeff,
+                             int grid, int degree, int coeff_per_head, vitpe_stream_t stream);
+int vitpe_attention_core_bwd(int dtype, const void* qkv, const void* dout, void* dqkv, int B, int N, int H,
+                             int HD, int mode, const float* cos, const float* sin, const float* table,
+                             const float* coeff, int grid, int degree, int coeff_per_head, float* dtable,
+                             float* dcoeff, float* dfreqs, vitpe_stream_t stream);
+
 /* ---- GEMMs ------------------------------------------------------------------------------
  * vitpe_gemm_nt: C[M,N] = epi(A[M,K] W[N,K]^T).  nn.Linear forward (vit.py:35,37; timm Mlp
  * fc1/fc2), nn.Conv2d-as-GEMM patch embed (vit.py:164,248), and -- on a transposed weight

@@ -205,9 +205,9 @@ def test_layernorm_fwd_bwd(K, dt, M, D):
 ATTN_MODES = ["none", "relative", "polynomial", "polynomial_perhead", "rope-axial", "rope-mixed"]
 
 
-def attn_case(mode, D, H, B, seed=0):
-    """inputs + oracle outputs for the fused attention op (N=65, hd=32)."""
-    N, hd, G = 65, D // H, 8
+def attn_case(mode, D, H, B, seed=0, G=8):
+    """inputs + oracle outputs for the attention ops (default N=65: 32x32 images, patch 4)."""
+    N, hd = G * G + 1, D // H
     xn = rnd(B, N, D, seed=seed + 1)
     wqkv = rnd(3 * D, D, seed=seed + 2, scale=0.3)
     dout = rnd(B, N, D, seed=seed + 3)
@@ -293,6 +293,68 @@ def test_fused_attention_bwd(K, dt, mode, D, H, B):
         assert rel_err(dcoef.cpu(), g_ref["coeff"]) < tol(dt)
     if mode == "rope-mixed":
         assert rel_err(dfr.cpu(), g_ref["freqs"]) < max(tol(dt), 2e-4)
+
+
+# attention core on a qkv buffer: CIFAR geometry (N=65, hd=32) and the ImageNet-shaped one of
+# BASELINE config 5 (N=197, hd=64; d reduced to 2 heads x 64 so that the oracle stays fast -- the
+# kernel's work is per (image, head) and independent of the number of heads)
+CORE_SHAPES = [(192, 6, 2, 8), (128, 2, 2, 14), (768, 12, 1, 14)]
+
+
+def core_qkv(xn, wqkv, dt):
+    return torch.nn.functional.linear(q(xn, dt), q(wqkv, dt))
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ATTN_MODES)
+@pytest.mark.parametrize("D,H,B,G", CORE_SHAPES)
+def test_attention_core_fwd(K, dt, mode, D, H, B, G):
+    N, hd, G, xn, wqkv, dout, pe = attn_case(mode, D, H, B, seed=20, G=G)
+    wqkv = wqkv * (0.3 if D > 200 else 1.0)
+    ref, _, _ = oracle_attn(mode, xn, wqkv, dout, pe, H, dt)
+    t = device_pe(K, mode, pe, H, G)
+    out = K.attention_core_fwd(dev(core_qkv(xn, wqkv, dt), DT[dt]), H, t)
+    # bf16: the oracle keeps qkv in fp32, the device buffer is rounded to bf16 first
+    assert rel_err(out.float().cpu(), ref) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ATTN_MODES)
+@pytest.mark.parametrize("D,H,B,G", CORE_SHAPES)
+def test_attention_core_bwd(K, dt, mode, D, H, B, G):
+    N, hd, G, xn, wqkv, dout, pe = attn_case(mode, D, H, B, seed=30, G=G)
+    wqkv = wqkv * (0.3 if D > 200 else 1.0)
+    _, dqkv_ref, g_ref = oracle_attn(mode, xn, wqkv, dout, pe, H, dt)
+    t = device_pe(K, mode, pe, H, G)
+    dtab = torch.zeros(H, 2 * N - 1, device="cuda") if mode == "relative" else None
+    dcoef = torch.zeros_like(dev(pe["coeff"])) if mode.startswith("polynomial") else None
+    dfr = torch.zeros(2, H, hd // 2, device="cuda") if mode == "rope-mixed" else None
+    dqkv = K.attention_core_bwd(dev(core_qkv(xn, wqkv, dt), DT[dt]), dev(dout, DT[dt]), H, t, dtab, dcoef, dfr)
+    assert rel_err(dqkv.float().cpu(), dqkv_ref) < tol(dt)
+    if mode == "relative":
+        assert rel_err(dtab.cpu(), g_ref["table"]) < tol(dt)
+    if mode.startswith("polynomial"):
+        assert rel_err(dcoef.cpu(), g_ref["coeff"]) < tol(dt)
+    if mode == "rope-mixed":
+        assert rel_err(dfr.cpu(), g_ref["freqs"]) < max(tol(dt), 2e-4)
+
+
+def test_attention_core_matches_fused_kernel(K):
+    """Same geometry through both paths (bf16): the two kernels share the tile math."""
+    mode, D, H, B = "rope-axial", 192, 6, 4
+    N, hd, G, xn, wqkv, dout, pe = attn_case(mode, D, H, B, seed=40)
+    t = device_pe(K, mode, pe, H, G)
+    xb, wb = dev(xn, torch.bfloat16), dev(wqkv, torch.bfloat16)
+    fused = K.fused_attention_fwd(xb, K.pack_qkv_weights(dev(wqkv), torch.bfloat16, H), H, t)
+    core = K.attention_core_fwd(K.linear(xb.reshape(B * N, D), wb).reshape(B, N, 3 * D), H, t)
+    assert rel_err(core.float().cpu(), fused.float().cpu()) < 2e-2
+
+
+def test_attention_core_unsupported_shape_is_an_error(K):
+    from vitpe._lib import VitpeError
+    from vitpe.kernels import PETables
+    with pytest.raises(VitpeError):
+        K.attention_core_fwd(torch.zeros(1, 17, 3 * 64, device="cuda"), 2, PETables("none", 4))
 
 
 def test_pack_qkv_weights_layout(K):

@@ -1,0 +1,142 @@
+// Device-side pieces shared by the fused attention kernels (attn.hip: projection fused, whole
+// image per workgroup) and the general attention core (attn_core.hip: one workgroup per
+// (image, head), q/k/v read from a qkv buffer).
+#pragma once
+#include "common.h"
+
+namespace vitpe {
+
+struct AttnArgs {
+  const void* xn;      // [B,N,D] T, layer-normed tokens
+  const void* wqkv;    // attn.qkv.weight [3D,D] packed fragment-major by vitpe_pack_qkv_weights (T)
+  void* out;           // fwd: [B,N,D] T merged heads ; bwd: d_qkv [B,N,3D] T
+  const void* dout;    // bwd: [B,N,D] T gradient of the merged-head output
+  const float* cos;    // rope: axial [P,HD/2], mixed [H,P,HD/2] (contiguous)
+  const float* sin;
+  const float* table;  // relative: [H,2N-1]
+  const float* coeff;  // polynomial: [deg+1] or [H,deg+1]
+  float* dtable;       // bwd relative: [H,2N-1] accumulated (atomics)
+  float* dcoeff;       // bwd polynomial: same shape as coeff, accumulated
+  float* dfreqs;       // bwd rope-mixed: [2,H,HD/2] accumulated
+  const void* qkv;     // attention core (attn_core.hip): [B,N,3*H*HD] T, output of the qkv projection
+  int B, N, H;
+  int mode, grid, degree, coeff_per_head;
+  float scale;
+  // optional fused LayerNorm (reference vit.py:113,122): xn = (x - mean[row]) * rstd[row] * gamma + beta is
+  // applied while staging; `xn` then points at the RAW tokens and xn_out (nullable) receives the
+  // normalised tokens for the backward pass
+  const float* ln_gamma;
+  const float* ln_beta;
+  const float* ln_mean;
+  const float* ln_rstd;
+  void* xn_out;
+  unsigned long long* census;  // debug: per workgroup {hw_id | xcc_id<<32, t_start, t_end} or null
+};
+
+constexpr int CENSUS_SLOTS = 32;
+// debug only (a.census == nullptr in every product launch): lane 0 of every wave stamps the
+// shader clock at phase boundaries: census[(wg*16 + wave)*CENSUS_SLOTS + slot]
+VITPE_DEV void census_stamp(const AttnArgs& a, int slot) {
+  if (a.census != nullptr && (threadIdx.x & 63) == 0) {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    unsigned long long* p = a.census + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * CENSUS_SLOTS;
+    if (slot == 0) {
+      unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, 32 bits
+      unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // HW_REG_XCC_ID
+      p[CENSUS_SLOTS - 1] = ((unsigned long long)xcc << 32) | hw;
+    }
+    p[slot] = t;
+  }
+}
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+// kernel-level PE classes (template parameter): what the logits / gradients need
+enum { KM_PLAIN = 0, KM_RELATIVE = 1, KM_POLY = 2, KM_ROPE = 3 };
+
+template <typename T, int HD, int D, int MT, int HPP, int NTOK>
+struct AttnCfg {
+  static constexpr int H = D / HD;
+  static constexpr int NT = HD / 16;              // 16-wide feature tiles per head
+  static constexpr int KS = D / 32;               // K32 chunks of the projection
+  static constexpr int HC = HD / 32;              // K32 chunks over the head dim
+  static constexpr int NP = 16 * MT;              // padded tokens
+  static constexpr int SC = (MT + 1) / 2;         // K32 chunks over tokens
+  static constexpr int VR = 32 * SC;              // rows incl. the zero tail read by 32-deep token contractions
+  static constexpr int LDX = D + Pad<T>::elems;
+  static constexpr int LDH = HD + Pad<T>::elems;
+  static constexpr int HSZ = VR * LDH;            // one (matrix, head) LDS tile with the zero tail
+  static constexpr int QSZ = NP * LDH;            // same without the tail (row-read operands only)
+  static constexpr int TABLD = 2 * NP;
+  static constexpr int MAXDEG = 7;
+  static constexpr int DD = D, HDD = HD, MTT = MT;
+  static_assert(HD % 32 == 0 && D % HD == 0 && D % 32 == 0, "shape");
+  static __device__ __forceinline__ int ntok(const AttnArgs& a) { return NTOK ? NTOK : a.N; }
+};
+
+// cross-group (lanes c, c+16, c+32, c+48) reductions on the VALU: v_permlane16_swap / 32_swap
+VITPE_DEV float xg_max(float v) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+VITPE_DEV float xg_sum(float v) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
+// additive logit bias (already multiplied by log2 e when staged) for (query i, key j) of head h
+template <typename C, int KM>
+VITPE_DEV float pe_bias2(const AttnArgs& a, const float* s_tab, const float* s_coef, int h, int i, int j, int N) {
+  if (KM == KM_RELATIVE) {
+    int idx = i - j + N - 1;  // positional_encoding.py:67-73 (1-D index incl. class token)
+    idx = max(0, min(idx, 2 * N - 2));
+    return s_tab[h * C::TABLD + idx];
+  }
+  if (KM == KM_POLY) {
+    if (i < 1 || j < 1) return 0.f;  // class row / column stay zero (positional_encoding.py:165-169)
+    const int pi = i - 1, pj = j - 1, G = a.grid;
+    const int l1 = abs(pi % G - pj % G) + abs(pi / G - pj / G);
+    const float* cf = s_coef + (a.coeff_per_head ? h * (C::MAXDEG + 1) : 0);
+    const float x = (float)l1;
+    float v = cf[a.degree];
+    for (int k = a.degree - 1; k >= 0; --k) v = v * x + cf[k];
+    return v;
+  }
+  return 0.f;
+}
+
+// ---- S^T tiles of one (head, query tile): logits in the exp2 domain, masked, + running max ----
+// s[jt][r] = log2e * (scale q_i.k_j + bias(i,j)),  j = 16jt+4g+r (key), i = 16it+c (query)
+template <typename T, typename C, int KM>
+VITPE_DEV float logits_T(const AttnArgs& a, const T* kh, const Frag<T>* bq, const float* s_tab, const float* s_coef,
+                         int h, int it, int lane, f32x4* s) {
+  constexpr int MT = C::MTT;
+  const int N = C::ntok(a);
+  const int c = lane & 15, g = lane >> 4;
+  const int i = 16 * it + c;
+  const T* krow = kh + c * C::LDH + 8 * g;
+  float m = -1e30f;
+#pragma unroll
+  for (int jt = 0; jt < MT; ++jt) {
+    s[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cs = 0; cs < C::HC; ++cs) mma(ld_frag(krow + 16 * jt * C::LDH + 32 * cs), bq[cs], s[jt]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 16 * jt + 4 * g + r;
+      float v = s[jt][r];
+      if (KM == KM_RELATIVE || KM == KM_POLY) v += pe_bias2<C, KM>(a, s_tab, s_coef, h, i, j, N);
+      if (jt == MT - 1) v = (j < N) ? v : -1e30f;  // padding keys only exist in the last tile
+      s[jt][r] = v;
+      m = fmaxf(m, v);
+    }
+  }
+  return xg_max(m);
+}
+
+}  // namespace vitpe

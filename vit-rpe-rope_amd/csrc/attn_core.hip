@@ -1,0 +1,541 @@
+// General attention core for geometries whose whole-image token tile does not fit one workgroup's
+// LDS (ImageNet-shaped ViT-B/16: N=197, hd=64, d=768 -- BASELINE.json config 5).
+//
+//   qkv = x Wqkv^T comes from vitpe_linear (panel GEMM);  this file does, per (image, head):
+//   split heads -> RoPE on q,k / relative or polynomial bias -> softmax(QK^T * hd^-0.5 + bias) -> .V
+//   -> merged-head output                        (reference models/vit.py:49-92, Attention.forward
+//                                                 after self.qkv(x) and before self.proj)
+//
+// One workgroup per (image, head).  K and V of the head live in LDS (bf16 N=197: 30 + 32 KB), the
+// query tile of a wave is read straight from the qkv buffer into MFMA operand registers with the
+// rotation and the folded scale applied in registers -- a q row is used by exactly one wave, staging
+// it through LDS would only add traffic.  The math of a (query tile) job is the one of attn.hip
+// (swapped S^T = K Q^T tiles, exp2-domain softmax, accumulator-as-operand P.V).
+//
+// Backward keeps two LDS tiles and refills them between its two steps:
+//   step 1 (query-tile jobs): K~ and V in LDS, q~/dO fragments from global: stats, dS^T, dQ
+//   step 2 (key-tile jobs)  : q~ and dO in LDS, k~/v fragments from global: dV, dK
+// so that fp32 (the 1e-4 parity mode) fits as well: 2 x 61 KB at N=197.
+#include "attn_common.h"
+
+namespace vitpe {
+
+// 16 bytes of row `rowp` (feature 0 of the head) at feature f0, rotated (rotate-half pairs
+// (f, f+HD/2), rope_utils.py:85-101) with this token's cos/sin row and scaled
+template <typename T, int HD, bool ROPE>
+VITPE_DEV Chunk16 ld_rot_chunk(const T* rowp, int f0, const float* cs, const float* sn, bool rot, float sc) {
+  constexpr int CHN = CH<T>::n;
+  const Chunk16 x = *reinterpret_cast<const Chunk16*>(rowp + f0);
+  if (!(ROPE && rot) && sc == 1.0f) return x;
+  float f[CHN];
+  chunk_to_f32<T>(x, f);
+  if (ROPE && rot) {
+    const bool lo = f0 < HD / 2;
+    const Chunk16 y = *reinterpret_cast<const Chunk16*>(rowp + (lo ? f0 + HD / 2 : f0 - HD / 2));
+    float p[CHN];
+    chunk_to_f32<T>(y, p);
+    const int ci = lo ? f0 : f0 - HD / 2;
+    const float sg = lo ? -1.f : 1.f;
+#pragma unroll
+    for (int t = 0; t < CHN; ++t) f[t] = f[t] * cs[ci + t] + sg * p[t] * sn[ci + t];
+  }
+#pragma unroll
+  for (int t = 0; t < CHN; ++t) f[t] *= sc;
+  return f32_to_chunk<T>(f);
+}
+
+// K32-chunk operand fragment (8 elements at feature f0) of a global row
+template <int HD, bool ROPE>
+VITPE_DEV Frag<bf16> ld_rot_frag(const bf16* rowp, int f0, const float* cs, const float* sn, bool rot, float sc) {
+  Frag<bf16> f;
+  f.v = __builtin_bit_cast(bf16x8, ld_rot_chunk<bf16, HD, ROPE>(rowp, f0, cs, sn, rot, sc));
+  return f;
+}
+template <int HD, bool ROPE>
+VITPE_DEV Frag<float> ld_rot_frag(const float* rowp, int f0, const float* cs, const float* sn, bool rot, float sc) {
+  Frag<float> f;
+  const Chunk16 a = ld_rot_chunk<float, HD, ROPE>(rowp, f0, cs, sn, rot, sc);
+  const Chunk16 b = ld_rot_chunk<float, HD, ROPE>(rowp, f0 + 4, cs, sn, rot, sc);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { f.v[t] = __uint_as_float(a[t]); f.v[4 + t] = __uint_as_float(b[t]); }
+  return f;
+}
+
+// rows of one head's matrix -> LDS tile [nrows][LDH]; rows >= N read as zero (token contractions
+// run over the padded tile)
+template <typename T, typename C, bool ROPE>
+VITPE_DEV void stage_rows(const AttnArgs& a, const T* src, int rstride, const float* cosb, const float* sinb, float sc,
+                          T* tile, int nrows, int tid, int nthreads) {
+  constexpr int CHN = CH<T>::n, HD = C::HDD, CPR = HD / CHN;
+  const int N = a.N;
+  for (int q = tid; q < nrows * CPR; q += nthreads) {
+    const int row = q / CPR, cc = q % CPR;
+    Chunk16 v = {0u, 0u, 0u, 0u};
+    if (row < N) {
+      const int tok = max(row, 1);  // class token (row 0) is never rotated
+      v = ld_rot_chunk<T, HD, ROPE>(src + (size_t)row * rstride, cc * CHN, cosb + (size_t)(tok - 1) * (HD / 2),
+                                    sinb + (size_t)(tok - 1) * (HD / 2), row >= 1, sc);
+    }
+    *reinterpret_cast<Chunk16*>(tile + row * C::LDH + cc * CHN) = v;
+  }
+}
+
+// bias table / coefficients of head hg, multiplied by log2 e (exp2-domain softmax)
+template <typename C, int KM>
+VITPE_DEV void stage_pe(const AttnArgs& a, int hg, float* s_tab, float* s_coef, int tid, int nthreads) {
+  const int N = a.N;
+  if (KM == KM_RELATIVE)
+    for (int i = tid; i < C::TABLD; i += nthreads)
+      s_tab[i] = (i < 2 * N - 1) ? a.table[(size_t)hg * (2 * N - 1) + i] * LOG2E : 0.f;
+  if (KM == KM_POLY)
+    for (int k = tid; k <= C::MAXDEG; k += nthreads) {
+      float v = 0.f;
+      if (k <= a.degree) v = a.coeff_per_head ? a.coeff[hg * (a.degree + 1) + k] : a.coeff[k];
+      s_coef[k] = v * LOG2E;
+    }
+}
+
+// =========================================================================================
+// Forward: NW = MT waves, one query tile each
+// =========================================================================================
+template <typename T, int HD, int MT, int KM, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_core_fwd_kernel(AttnArgs a) {
+  using C = AttnCfg<T, HD, HD, MT, 1, 0>;
+  constexpr bool ROPE = (KM == KM_ROPE);
+  __shared__ __attribute__((aligned(16))) T kt[C::QSZ];  // K~ (row reads only)
+  __shared__ __attribute__((aligned(16))) T vt[C::HSZ];  // V (column reads run into the zero tail)
+  __shared__ __attribute__((aligned(16))) float s_tab[KM == KM_RELATIVE ? C::TABLD : 4];
+  __shared__ float s_coef[C::MAXDEG + 1];
+
+  const int N = a.N, H = a.H, Dr = H * HD, P = N - 1;
+  const int b = blockIdx.x / H, hg = blockIdx.x % H;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const T* qg = reinterpret_cast<const T*>(a.qkv) + (size_t)b * N * 3 * Dr + hg * HD;
+  const size_t hoff = (ROPE && a.mode == PE_ROPE_MIXED) ? (size_t)hg * P * (HD / 2) : 0;
+  const float* cosb = ROPE ? a.cos + hoff : nullptr;
+  const float* sinb = ROPE ? a.sin + hoff : nullptr;
+
+  stage_rows<T, C, ROPE>(a, qg + Dr, 3 * Dr, cosb, sinb, 1.0f, kt, C::NP, threadIdx.x, 64 * NW);
+  stage_rows<T, C, false>(a, qg + 2 * Dr, 3 * Dr, nullptr, nullptr, 1.0f, vt, C::VR, threadIdx.x, 64 * NW);
+  stage_pe<C, KM>(a, hg, s_tab, s_coef, threadIdx.x, 64 * NW);
+  __syncthreads();
+
+  T* outp = reinterpret_cast<T*>(a.out) + (size_t)b * N * Dr + hg * HD;
+  for (int it = wave; it < MT; it += NW) {
+    const int i = 16 * it + c, il = min(i, N - 1), tok = max(il, 1);
+    Frag<T> bq[C::HC];
+#pragma unroll
+    for (int cs = 0; cs < C::HC; ++cs)
+      bq[cs] = ld_rot_frag<HD, ROPE>(qg + (size_t)il * 3 * Dr, 32 * cs + 8 * g, cosb + (size_t)(tok - 1) * (HD / 2),
+                                     sinb + (size_t)(tok - 1) * (HD / 2), il >= 1, a.scale * LOG2E);
+    f32x4 s[MT];
+    const float m = logits_T<T, C, KM>(a, kt, bq, s_tab, s_coef, 0, it, lane, s);
+    float l = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[jt][r] - m);
+        s[jt][r] = p;
+        l += p;
+      }
+    l = xg_sum(l);
+    f32x4 o[C::NT];
+#pragma unroll
+    for (int dt = 0; dt < C::NT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sc = 0; sc < C::SC; ++sc) {
+      const Frag<T> bp = acc_to_frag<T>(s[2 * sc], (2 * sc + 1 < MT) ? s[(2 * sc + 1 < MT) ? 2 * sc + 1 : 0] : z4);
+#pragma unroll
+      for (int dt = 0; dt < C::NT; ++dt)
+        mma(ld_frag_tr(vt, C::LDH, 32 * sc + 4 * g, 32 * sc + 16 + 4 * g, 16 * dt), bp, o[dt]);
+    }
+    const float inv = __builtin_amdgcn_rcpf(l);
+    if (i < N) {
+#pragma unroll
+      for (int dt = 0; dt < C::NT; ++dt)
+        st4(outp + (size_t)i * Dr + 16 * dt + 4 * g, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+    }
+  }
+}
+
+// =========================================================================================
+// Backward
+// =========================================================================================
+constexpr int CORE_HMAX = 16;  // heads, for the RoPE-mixed frequency-gradient scratch
+
+template <typename T, int HD, int MT, int KM, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_core_bwd_kernel(AttnArgs a) {
+  using C = AttnCfg<T, HD, HD, MT, 1, 0>;
+  constexpr bool ROPE = (KM == KM_ROPE);
+  constexpr int NTH = 64 * NW;
+  __shared__ __attribute__((aligned(16))) T t0[C::HSZ];  // step 1: K~ ; step 2: q~
+  __shared__ __attribute__((aligned(16))) T t1[C::HSZ];  // step 1: V  ; step 2: dO
+  __shared__ __attribute__((aligned(16))) float s_tab[KM == KM_RELATIVE ? C::TABLD : 4];
+  __shared__ float s_coef[C::MAXDEG + 1];
+  __shared__ __attribute__((aligned(16))) float s_stat[2 * C::NP];  // [lse2 | delta][token]
+  __shared__ float s_dtab[KM == KM_RELATIVE ? C::TABLD : 4];
+  __shared__ float s_dcoef[C::MAXDEG + 1];
+  __shared__ float s_dfreq[ROPE ? 2 * CORE_HMAX * (HD / 2) : 4];
+
+  const int N = a.N, H = a.H, Dr = H * HD, P = N - 1;
+  const int b = blockIdx.x / H, hg = blockIdx.x % H;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const T* qg = reinterpret_cast<const T*>(a.qkv) + (size_t)b * N * 3 * Dr + hg * HD;
+  const T* dog = reinterpret_cast<const T*>(a.dout) + (size_t)b * N * Dr + hg * HD;
+  T* dq = reinterpret_cast<T*>(a.out) + (size_t)b * N * 3 * Dr + hg * HD;
+  const bool mixed = ROPE && a.mode == PE_ROPE_MIXED;
+  const size_t hoff = mixed ? (size_t)hg * P * (HD / 2) : 0;
+  const float* cosb = ROPE ? a.cos + hoff : nullptr;
+  const float* sinb = ROPE ? a.sin + hoff : nullptr;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const float qsc = a.scale * LOG2E;
+
+  stage_rows<T, C, ROPE>(a, qg + Dr, 3 * Dr, cosb, sinb, 1.0f, t0, C::VR, threadIdx.x, NTH);
+  stage_rows<T, C, false>(a, qg + 2 * Dr, 3 * Dr, nullptr, nullptr, 1.0f, t1, C::NP, threadIdx.x, NTH);
+  stage_pe<C, KM>(a, hg, s_tab, s_coef, threadIdx.x, NTH);
+  if (KM == KM_RELATIVE)
+    for (int q = threadIdx.x; q < C::TABLD; q += NTH) s_dtab[q] = 0.f;
+  for (int q = threadIdx.x; q <= C::MAXDEG; q += NTH) s_dcoef[q] = 0.f;
+  if (ROPE)
+    for (int q = threadIdx.x; q < 2 * CORE_HMAX * (HD / 2); q += NTH) s_dfreq[q] = 0.f;
+  __syncthreads();
+
+  // ---- step 1: query-tile jobs on the swapped tiles: stats, dS^T, dQ -----------------------
+  for (int it = wave; it < MT; it += NW) {
+    const T* kh = t0;
+    const T* vh = t1;
+    const int i = 16 * it + c, il = min(i, N - 1), tok = max(il, 1);
+    const float* csr = cosb + (size_t)(tok - 1) * (HD / 2);
+    const float* snr = sinb + (size_t)(tok - 1) * (HD / 2);
+    Frag<T> bq[C::HC], bdo[C::HC];
+#pragma unroll
+    for (int cs = 0; cs < C::HC; ++cs) {
+      bq[cs] = ld_rot_frag<HD, ROPE>(qg + (size_t)il * 3 * Dr, 32 * cs + 8 * g, csr, snr, il >= 1, qsc);
+      bdo[cs] = ld_rot_frag<HD, false>(dog + (size_t)il * Dr, 32 * cs + 8 * g, nullptr, nullptr, false, 1.0f);
+    }
+    f32x4 s[MT], dp[MT];
+    const float m = logits_T<T, C, KM>(a, kh, bq, s_tab, s_coef, 0, it, lane, s);
+    if (MT > 8) __builtin_amdgcn_sched_barrier(0);
+    const T* vrow = vh + c * C::LDH + 8 * g;
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt) {
+      dp[jt] = z4;
+#pragma unroll
+      for (int cs = 0; cs < C::HC; ++cs) mma(ld_frag(vrow + 16 * jt * C::LDH + 32 * cs), bdo[cs], dp[jt]);
+      if (MT > 8 && (jt & 1)) __builtin_amdgcn_sched_barrier(0);  // bound the load hoisting (register pressure)
+    }
+    float l = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[jt][r] - m);
+        s[jt][r] = p;
+        l += p;
+      }
+    l = xg_sum(l);
+    const float inv = __builtin_amdgcn_rcpf(l);
+    float dl = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[jt][r] *= inv;
+        dl += s[jt][r] * dp[jt][r];
+      }
+    dl = xg_sum(dl);
+    if (g == 0) {
+      s_stat[0 * C::NP + i] = m + __builtin_amdgcn_logf(l);  // v_log_f32 = log2
+      s_stat[1 * C::NP + i] = dl;
+    }
+    float cacc[C::MAXDEG + 1];
+#pragma unroll
+    for (int k = 0; k <= C::MAXDEG; ++k) cacc[k] = 0.f;
+    const bool qvalid = i < N;
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * jt + 4 * g + r;
+        const bool valid = qvalid && ((jt < MT - 1) || (j < N));
+        const float ds = valid ? s[jt][r] * (dp[jt][r] - dl) : 0.f;
+        dp[jt][r] = ds;
+        if (KM == KM_RELATIVE) {
+          if (valid) atomicAdd(&s_dtab[i - j + N - 1], ds);
+        } else if (KM == KM_POLY) {
+          if (valid && i >= 1 && j >= 1) {
+            const int pi = i - 1, pj = j - 1, G = a.grid;
+            const float x = (float)(abs(pi % G - pj % G) + abs(pi / G - pj / G));
+            float pw = 1.f;
+#pragma unroll
+            for (int k = 0; k <= C::MAXDEG; ++k) {
+              if (k <= a.degree) cacc[k] += ds * pw;
+              pw *= x;
+            }
+          }
+        }
+      }
+    if (KM == KM_POLY) {
+#pragma unroll
+      for (int k = 0; k <= C::MAXDEG; ++k) {
+        if (k <= a.degree) {  // wave-uniform
+          const float t = wave_sum(cacc[k]);
+          if (lane == 0) atomicAdd(&s_dcoef[k], t);
+        }
+      }
+    }
+    // dQrot^T[d][i] / scale = sum_j K~^T[d][j] dS^T[j][i]
+    f32x4 dqa[C::NT];
+#pragma unroll
+    for (int dt = 0; dt < C::NT; ++dt) dqa[dt] = z4;
+#pragma unroll
+    for (int sc = 0; sc < C::SC; ++sc) {
+      const Frag<T> bs = acc_to_frag<T>(dp[2 * sc], (2 * sc + 1 < MT) ? dp[(2 * sc + 1 < MT) ? 2 * sc + 1 : 0] : z4);
+#pragma unroll
+      for (int dt = 0; dt < C::NT; ++dt)
+        mma(ld_frag_tr(kh, C::LDH, 32 * sc + 4 * g, 32 * sc + 16 + 4 * g, 16 * dt), bs, dqa[dt]);
+      if (MT > 8) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ROPE && i >= 1 && i < N) {
+#pragma unroll
+      for (int nt = 0; nt < C::NT / 2; ++nt) {
+        const f32x4 cs = *reinterpret_cast<const f32x4*>(csr + 16 * nt + 4 * g);
+        const f32x4 sn = *reinterpret_cast<const f32x4*>(snr + 16 * nt + 4 * g);
+        if (mixed) {
+          // dL/dphase = (dq~2 q~1 - dq~1 q~2), q~ = scale*log2e*rot(q) (see attn.hip): ln2 undoes the log2e
+          const f32x4 x1 = ld4(qg + (size_t)i * 3 * Dr + 16 * nt + 4 * g);
+          const f32x4 x2 = ld4(qg + (size_t)i * 3 * Dr + 16 * (nt + C::NT / 2) + 4 * g);
+          const int flat = (i - 1) * H + hg;  // view-scramble: slot [h, i-1] holds head flat/P at pos flat%P
+          const int hs = flat / P, ps = flat % P;
+          const float tx = (float)(ps % a.grid) * LN2, ty = (float)(ps / a.grid) * LN2;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float q1 = (x1[r] * cs[r] - x2[r] * sn[r]) * qsc, q2 = (x1[r] * sn[r] + x2[r] * cs[r]) * qsc;
+            const float dph = dqa[nt + C::NT / 2][r] * q1 - dqa[nt][r] * q2;
+            atomicAdd(&s_dfreq[(0 * H + hs) * (HD / 2) + 16 * nt + 4 * g + r], tx * dph);
+            atomicAdd(&s_dfreq[(1 * H + hs) * (HD / 2) + 16 * nt + 4 * g + r], ty * dph);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d1 = dqa[nt][r], d2 = dqa[nt + C::NT / 2][r];
+          dqa[nt][r] = d1 * cs[r] + d2 * sn[r];
+          dqa[nt + C::NT / 2][r] = -d1 * sn[r] + d2 * cs[r];
+        }
+      }
+    }
+    if (i < N) {
+#pragma unroll
+      for (int dt = 0; dt < C::NT; ++dt)
+        st4(dq + (size_t)i * 3 * Dr + 16 * dt + 4 * g, dqa[dt][0] * a.scale, dqa[dt][1] * a.scale, dqa[dt][2] * a.scale,
+            dqa[dt][3] * a.scale);
+    }
+  }
+  __syncthreads();
+  // refill: q~ and dO with zero tails (token contractions of step 2)
+  stage_rows<T, C, ROPE>(a, qg, 3 * Dr, cosb, sinb, qsc, t0, C::VR, threadIdx.x, NTH);
+  stage_rows<T, C, false>(a, dog, Dr, nullptr, nullptr, 1.0f, t1, C::VR, threadIdx.x, NTH);
+  __syncthreads();
+
+  // ---- step 2: key-tile jobs on the plain tiles: dV, dK -------------------------------------
+  for (int jt = wave; jt < MT; jt += NW) {
+    const T* qh = t0;
+    const T* doh = t1;
+    const int j = 16 * jt + c, jl = min(j, N - 1), tok = max(jl, 1);
+    const float* csr = cosb + (size_t)(tok - 1) * (HD / 2);
+    const float* snr = sinb + (size_t)(tok - 1) * (HD / 2);
+    Frag<T> bk[C::HC], bv[C::HC];
+#pragma unroll
+    for (int cs = 0; cs < C::HC; ++cs) {
+      bk[cs] = ld_rot_frag<HD, ROPE>(qg + Dr + (size_t)jl * 3 * Dr, 32 * cs + 8 * g, csr, snr, jl >= 1, 1.0f);
+      bv[cs] = ld_rot_frag<HD, false>(qg + 2 * Dr + (size_t)jl * 3 * Dr, 32 * cs + 8 * g, nullptr, nullptr, false, 1.0f);
+    }
+    const bool kvalid = j < N;
+    const T* qrow = qh + c * C::LDH + 8 * g;
+    const T* dorow = doh + c * C::LDH + 8 * g;
+    f32x4 dva[C::NT], dka[C::NT];
+#pragma unroll
+    for (int dt = 0; dt < C::NT; ++dt) { dva[dt] = z4; dka[dt] = z4; }
+    // the row statistics are known here, so the query tiles stream through in pairs (one K32 chunk
+    // of the token contraction): only two P / dS tiles are live at a time
+#pragma unroll
+    for (int sc = 0; sc < C::SC; ++sc) {
+      f32x4 p[2], ds[2];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int it = 2 * sc + hf;
+        p[hf] = z4;
+        ds[hf] = z4;
+        if (it < MT) {
+#pragma unroll
+          for (int cs = 0; cs < C::HC; ++cs) {
+            mma(ld_frag(qrow + 16 * it * C::LDH + 32 * cs), bk[cs], p[hf]);
+            mma(ld_frag(dorow + 16 * it * C::LDH + 32 * cs), bv[cs], ds[hf]);
+          }
+          const f32x4 lse = *reinterpret_cast<const f32x4*>(&s_stat[0 * C::NP + 16 * it + 4 * g]);
+          const f32x4 dl = *reinterpret_cast<const f32x4*>(&s_stat[1 * C::NP + 16 * it + 4 * g]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * it + 4 * g + r;
+            float sv = p[hf][r];
+            if (KM == KM_RELATIVE || KM == KM_POLY) sv += pe_bias2<C, KM>(a, s_tab, s_coef, 0, i, j, N);
+            const bool valid = kvalid && ((it < MT - 1) || (i < N));
+            const float pv = valid ? __builtin_amdgcn_exp2f(sv - lse[r]) : 0.f;
+            p[hf][r] = pv;
+            ds[hf][r] = pv * (ds[hf][r] - dl[r]);
+          }
+        }
+      }
+      const Frag<T> bp = acc_to_frag<T>(p[0], p[1]);
+      const Frag<T> bs = acc_to_frag<T>(ds[0], ds[1]);
+#pragma unroll
+      for (int dt = 0; dt < C::NT; ++dt) {
+        mma(ld_frag_tr(doh, C::LDH, 32 * sc + 4 * g, 32 * sc + 16 + 4 * g, 16 * dt), bp, dva[dt]);
+        mma(ld_frag_tr(qh, C::LDH, 32 * sc + 4 * g, 32 * sc + 16 + 4 * g, 16 * dt), bs, dka[dt]);
+      }
+      if (MT > 8) __builtin_amdgcn_sched_barrier(0);
+    }
+    // dK_rot = dS^T q~ / log2e  (q~ carries the folded scale and log2e)
+#pragma unroll
+    for (int dt = 0; dt < C::NT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dka[dt][r] *= LN2;
+    if (ROPE && j >= 1 && j < N) {
+#pragma unroll
+      for (int nt = 0; nt < C::NT / 2; ++nt) {
+        const f32x4 cs = *reinterpret_cast<const f32x4*>(csr + 16 * nt + 4 * g);
+        const f32x4 sn = *reinterpret_cast<const f32x4*>(snr + 16 * nt + 4 * g);
+        if (mixed) {
+          const f32x4 x1 = ld4(qg + Dr + (size_t)j * 3 * Dr + 16 * nt + 4 * g);
+          const f32x4 x2 = ld4(qg + Dr + (size_t)j * 3 * Dr + 16 * (nt + C::NT / 2) + 4 * g);
+          const int flat = (j - 1) * H + hg;
+          const int hs = flat / P, ps = flat % P;
+          const float tx = (float)(ps % a.grid), ty = (float)(ps / a.grid);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float k1 = x1[r] * cs[r] - x2[r] * sn[r], k2 = x1[r] * sn[r] + x2[r] * cs[r];
+            const float dph = dka[nt + C::NT / 2][r] * k1 - dka[nt][r] * k2;
+            atomicAdd(&s_dfreq[(0 * H + hs) * (HD / 2) + 16 * nt + 4 * g + r], tx * dph);
+            atomicAdd(&s_dfreq[(1 * H + hs) * (HD / 2) + 16 * nt + 4 * g + r], ty * dph);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d1 = dka[nt][r], d2 = dka[nt + C::NT / 2][r];
+          dka[nt][r] = d1 * cs[r] + d2 * sn[r];
+          dka[nt + C::NT / 2][r] = -d1 * sn[r] + d2 * cs[r];
+        }
+      }
+    }
+    if (j < N) {
+#pragma unroll
+      for (int dt = 0; dt < C::NT; ++dt) {
+        st4(dq + Dr + (size_t)j * 3 * Dr + 16 * dt + 4 * g, dka[dt][0], dka[dt][1], dka[dt][2], dka[dt][3]);
+        st4(dq + 2 * Dr + (size_t)j * 3 * Dr + 16 * dt + 4 * g, dva[dt][0], dva[dt][1], dva[dt][2], dva[dt][3]);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- flush this (image, head)'s positional-parameter gradients ----------------------------
+  if (KM == KM_RELATIVE) {
+    for (int q = threadIdx.x; q < 2 * N - 1; q += NTH) atomicAdd(a.dtable + (size_t)hg * (2 * N - 1) + q, s_dtab[q]);
+  } else if (KM == KM_POLY) {
+    for (int k = threadIdx.x; k <= a.degree; k += NTH)
+      atomicAdd(a.dcoeff + (a.coeff_per_head ? hg * (a.degree + 1) : 0) + k, s_dcoef[k]);
+  } else if (mixed) {
+    for (int q = threadIdx.x; q < 2 * H * (HD / 2); q += NTH)
+      if (s_dfreq[q] != 0.f) atomicAdd(a.dfreqs + q, s_dfreq[q]);
+  }
+}
+
+}  // namespace vitpe
+
+using namespace vitpe;
+
+template <typename T, int HD, int MT>
+static int launch_core(bool bwd, const AttnArgs& a, hipStream_t s) {
+  // forward: one wave per query tile; backward: half as many waves (two rounds) so that the
+  // p/dS accumulators of a key-tile job (2*MT f32x4) stay in registers
+  constexpr int NWF = MT, NWB = (MT > 8) ? (MT + 1) / 2 : MT;
+  const dim3 grid((unsigned)(a.B * a.H));
+#define VITPE_CORE_LAUNCH(KM)                                                                                      \
+  do {                                                                                                               \
+    if (bwd) hipLaunchKernelGGL((attn_core_bwd_kernel<T, HD, MT, KM, NWB>), grid, dim3(64 * NWB), 0, s, a);          \
+    else hipLaunchKernelGGL((attn_core_fwd_kernel<T, HD, MT, KM, NWF>), grid, dim3(64 * NWF), 0, s, a);              \
+  } while (0)
+  switch (a.mode) {
+    case PE_RELATIVE: VITPE_CORE_LAUNCH(KM_RELATIVE); break;
+    case PE_POLY: VITPE_CORE_LAUNCH(KM_POLY); break;
+    case PE_ROPE_AXIAL:
+    case PE_ROPE_MIXED: VITPE_CORE_LAUNCH(KM_ROPE); break;
+    default: VITPE_CORE_LAUNCH(KM_PLAIN); break;
+  }
+#undef VITPE_CORE_LAUNCH
+  VITPE_CHECK_LAUNCH();
+}
+
+static int dispatch_core(bool bwd, int dtype, int HD, const AttnArgs& a, hipStream_t s) {
+  const int MT = (a.N + 15) / 16;
+  if (dtype == 1) {
+    if (HD == 64 && MT == 13) return launch_core<bf16, 64, 13>(bwd, a, s);
+    if (HD == 32 && MT == 5) return launch_core<bf16, 32, 5>(bwd, a, s);
+  } else if (dtype == 0) {
+    if (HD == 64 && MT == 13) return launch_core<float, 64, 13>(bwd, a, s);
+    if (HD == 32 && MT == 5) return launch_core<float, 32, 5>(bwd, a, s);
+  }
+  return (int)hipErrorNotSupported;
+}
+
+extern "C" int vitpe_attention_core_supported(int dtype, int N, int HD) {
+  const int MT = (N + 15) / 16;
+  return (dtype == 0 || dtype == 1) && N >= 2 && ((HD == 64 && MT == 13) || (HD == 32 && MT == 5));
+}
+
+static int core_check_pe(int mode, const float* cos, const float* sin, const float* table, const float* coeff, int N,
+                         int H, int grid, int degree) {
+  if (mode == PE_ROPE_AXIAL || mode == PE_ROPE_MIXED) {
+    if (!cos || !sin || grid * grid != N - 1) return 0;
+    if (mode == PE_ROPE_MIXED && H > CORE_HMAX) return 0;
+  }
+  if (mode == PE_RELATIVE && !table) return 0;
+  if (mode == PE_POLY && (!coeff || degree < 0 || degree > 7 || grid * grid != N - 1)) return 0;
+  return mode >= PE_NONE && mode <= PE_ROPE_MIXED;
+}
+
+extern "C" int vitpe_attention_core_fwd(int dtype, const void* qkv, void* out, int B, int N, int H, int HD, int mode,
+                                        const float* cos, const float* sin, const float* table, const float* coeff,
+                                        int grid, int degree, int coeff_per_head, hipStream_t stream) {
+  VITPE_REQUIRE(qkv && out && B >= 0 && N >= 2 && H >= 1);
+  VITPE_REQUIRE(core_check_pe(mode, cos, sin, table, coeff, N, H, grid, degree));
+  if (B == 0) return 0;
+  AttnArgs a{};
+  a.qkv = qkv; a.out = out; a.cos = cos; a.sin = sin; a.table = table; a.coeff = coeff;
+  a.B = B; a.N = N; a.H = H; a.mode = mode; a.grid = grid; a.degree = degree; a.coeff_per_head = coeff_per_head;
+  a.scale = 1.0f / sqrtf((float)HD);
+  return dispatch_core(false, dtype, HD, a, stream);
+}
+
+extern "C" int vitpe_attention_core_bwd(int dtype, const void* qkv, const void* dout, void* dqkv, int B, int N, int H,
+                                        int HD, int mode, const float* cos, const float* sin, const float* table,
+                                        const float* coeff, int grid, int degree, int coeff_per_head, float* dtable,
+                                        float* dcoeff, float* dfreqs, hipStream_t stream) {
+  VITPE_REQUIRE(qkv && dout && dqkv && B >= 0 && N >= 2 && H >= 1);
+  VITPE_REQUIRE(core_check_pe(mode, cos, sin, table, coeff, N, H, grid, degree));
+  if (mode == PE_RELATIVE) VITPE_REQUIRE(dtable);
+  if (mode == PE_POLY) VITPE_REQUIRE(dcoeff);
+  if (mode == PE_ROPE_MIXED) VITPE_REQUIRE(dfreqs);
+  if (B == 0) return 0;
+  AttnArgs a{};
+  a.qkv = qkv; a.dout = dout; a.out = dqkv; a.cos = cos; a.sin = sin; a.table = table; a.coeff = coeff;
+  a.dtable = dtable; a.dcoeff = dcoeff; a.dfreqs = dfreqs;
+  a.B = B; a.N = N; a.H = H; a.mode = mode; a.grid = grid; a.degree = degree; a.coeff_per_head = coeff_per_head;
+  a.scale = 1.0f / sqrtf((float)HD);
+  return dispatch_core(true, dtype, HD, a, stream);
+}

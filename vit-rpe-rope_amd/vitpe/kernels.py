@@ -209,6 +209,36 @@ def fused_attention_bwd(xn, wqkv, dout, num_heads, pe: PETables, dtable=None, dc
     return dqkv
 
 
+def attention_core_supported(dtype, N, HD):
+    return bool(lib().vitpe_attention_core_supported(dtype_code(dtype), N, HD))
+
+
+def attention_core_fwd(qkv, num_heads, pe: PETables, out=None):
+    """qkv [B,N,3D] (output of the qkv Linear) -> merged heads [B,N,D]; one workgroup per (image, head)."""
+    require_device(qkv, out)
+    B, N, D3 = qkv.shape
+    D = D3 // 3
+    HD = D // num_heads
+    o = out if out is not None else torch.empty((B, N, D), dtype=qkv.dtype, device=qkv.device)
+    check(lib().vitpe_attention_core_fwd(dtype_code(qkv.dtype), ptr(qkv), ptr(o), B, N, num_heads, HD, pe.code,
+                                         ptr(pe.cos), ptr(pe.sin), ptr(pe.table), ptr(pe.coeff), pe.grid, pe.degree,
+                                         int(pe.coeff_per_head), stream_ptr()), "vitpe_attention_core_fwd")
+    return o
+
+
+def attention_core_bwd(qkv, dout, num_heads, pe: PETables, dtable=None, dcoeff=None, dfreqs=None, out=None):
+    """-> dqkv [B,N,3D]; PE-parameter gradients accumulated into dtable/dcoeff/dfreqs."""
+    require_device(qkv, dout, dtable, dcoeff, dfreqs, out)
+    B, N, D3 = qkv.shape
+    HD = D3 // 3 // num_heads
+    dqkv = out if out is not None else torch.empty_like(qkv)
+    check(lib().vitpe_attention_core_bwd(dtype_code(qkv.dtype), ptr(qkv), ptr(dout), ptr(dqkv), B, N, num_heads, HD,
+                                         pe.code, ptr(pe.cos), ptr(pe.sin), ptr(pe.table), ptr(pe.coeff), pe.grid,
+                                         pe.degree, int(pe.coeff_per_head), ptr(dtable), ptr(dcoeff), ptr(dfreqs),
+                                         stream_ptr()), "vitpe_attention_core_bwd")
+    return dqkv
+
+
 # ---- patch embed ----------------------------------------------------------------------------
 def unfold(images, patch, dtype, out=None):
     require_device(images, out)
