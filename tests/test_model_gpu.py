@@ -81,6 +81,40 @@ def test_mnist_shaped_config(golden):
     assert rel_err(model.patch_embed.weight.grad.cpu(), g["mnist/none/grad/patch_embed.weight"]) < 1e-3
 
 
+IMNET1 = dict(img_size=224, patch_size=16, embed_dim=768, depth=1, num_heads=12)
+
+
+def test_imagenet_shaped_block_vs_reference_golden(golden):
+    """BASELINE config 5 geometry (224/16, d=768, H=12, N=197, hd=64), one block: qkv Linear +
+    attention core instead of the CIFAR-only fused kernel; logits against the reference's own output."""
+    g = golden("model")
+    cfg, model = build("rope-axial", {}, IMNET1)
+    images, labels = O.closed_form_batch(cfg, 2)
+    with torch.no_grad():
+        logits = model(images.cuda())
+    assert rel_err(logits.cpu(), g["imnet1/rope-axial/logits"]) < 1e-4
+    loss = torch.ops.vitpe.cross_entropy(logits, labels.cuda())[0]
+    assert abs(float(loss) - float(g["imnet1/rope-axial/loss"])) < 1e-4
+
+
+@pytest.mark.parametrize("tag,extra", [m for m in MODES if m[0] in ("relative", "rope-mixed", "polynomial")])
+def test_imagenet_shaped_block_gradients_vs_oracle(tag, extra):
+    cfg, model = build(tag, extra, IMNET1)
+    images, labels = O.closed_form_batch(cfg, 2)
+    logits = model(images.cuda())
+    loss = torch.nn.CrossEntropyLoss()(logits, labels.cuda())
+    loss.backward()
+    params = O.closed_form_params(cfg)
+    ref_logits, ref_loss, ref_grads = O.loss_and_grads(cfg, params, images, labels)
+    assert rel_err(logits.detach().cpu(), ref_logits) < 1e-4
+    assert abs(float(loss) - float(ref_loss)) < 1e-4
+    for name, p_ in model.named_parameters():
+        mine, ref = p_.grad.cpu(), ref_grads[name]
+        if name == "pos_embed.pos_embed":
+            mine = mine[:, :ref.shape[1]]
+        assert rel_err(mine, ref) < 1e-3, name
+
+
 def test_attention_module_vs_reference_golden(golden):
     """The reference's Attention.forward fixture (dim 96, 3 heads, B 2): y, dx, dW, dPE."""
     from models.vit import Attention

@@ -74,36 +74,49 @@ layer_norm.register_autograd(_ln_backward, setup_context=_ln_setup)
 
 
 # ---- attention: y = [resid +] proj(fused_attention(xn)) ----------------------------------------
+def _fused_ok(xn: Tensor, num_heads: int) -> bool:
+    B, N, D = xn.shape
+    return bool(L.lib().vitpe_fused_attention_supported(L.dtype_code(xn.dtype), N, D, D // num_heads))
+
+
 @torch.library.custom_op("vitpe::attention", mutates_args=())
 def attention(xn: Tensor, wqkv: Tensor, wproj: Tensor, bproj: Tensor, resid: Optional[Tensor], num_heads: int,
               mode: int, grid: int, pe_param: Optional[Tensor], inv_freq: Optional[Tensor], degree: int,
-              per_head: bool) -> Tuple[Tensor, Tensor]:
+              per_head: bool) -> Tuple[Tensor, Tensor, Tensor]:
+    """-> (y, a, qkv).  CIFAR geometry: one fused kernel (qkv never leaves the chip, `qkv` is empty);
+    other geometries: qkv Linear (panel GEMM) + the per-(image, head) attention core."""
     dt = xn.dtype
     B, N, D = xn.shape
     t = _pe_tables(mode, grid, pe_param, inv_freq, degree, per_head)
-    a = K.fused_attention_fwd(xn.contiguous(), K.pack_qkv_weights(wqkv.contiguous(), dt, num_heads), num_heads, t)
+    if _fused_ok(xn, num_heads):
+        a = K.fused_attention_fwd(xn.contiguous(), K.pack_qkv_weights(wqkv.contiguous(), dt, num_heads), num_heads, t)
+        qkv = xn.new_empty(0)
+    else:
+        qkv = K.linear(xn.contiguous().view(B * N, D), _shadow(wqkv, dt), None, epi=L.EPI_BIAS).view(B, N, 3 * D)
+        a = K.attention_core_fwd(qkv, num_heads, t)
     if resid is None:
         y = K.linear(a.view(B * N, D), _shadow(wproj, dt), bproj, epi=L.EPI_BIAS)
     else:
         y = K.linear(a.view(B * N, D), _shadow(wproj, dt), bproj, epi=L.EPI_BIAS_RESID,
                       resid=resid.contiguous().view(B * N, D))
-    return y.view(B, N, D), a
+    return y.view(B, N, D), a, qkv
 
 
 @attention.register_fake
 def _(xn, wqkv, wproj, bproj, resid, num_heads, mode, grid, pe_param, inv_freq, degree, per_head):
-    return torch.empty_like(xn), torch.empty_like(xn)
+    B, N, D = xn.shape
+    return torch.empty_like(xn), torch.empty_like(xn), xn.new_empty(0)
 
 
 def _attn_setup(ctx, inputs, output):
     xn, wqkv, wproj, bproj, resid, num_heads, mode, grid, pe_param, inv_freq, degree, per_head = inputs
-    _, a = output
-    ctx.save_for_backward(xn, wqkv, wproj, a, pe_param, inv_freq)
+    _, a, qkv = output
+    ctx.save_for_backward(xn, wqkv, wproj, a, qkv, pe_param, inv_freq)
     ctx.meta = (num_heads, mode, grid, degree, per_head, resid is not None)
 
 
-def _attn_backward(ctx, dy, _da):
-    xn, wqkv, wproj, a, pe_param, inv_freq = ctx.saved_tensors
+def _attn_backward(ctx, dy, _da, _dqkv):
+    xn, wqkv, wproj, a, qkv, pe_param, inv_freq = ctx.saved_tensors
     num_heads, mode, grid, degree, per_head, has_resid = ctx.meta
     dt = xn.dtype
     B, N, D = xn.shape
@@ -113,15 +126,17 @@ def _attn_backward(ctx, dy, _da):
     dwproj = torch.zeros_like(wproj)
     dbproj = torch.zeros(D, dtype=torch.float32, device=dy.device)
     K.gemm_tn(dy2, a.view(B * N, D), dwproj, dbproj)
-    # fused attention backward -> dqkv (+ PE parameter grads)
+    # attention backward -> dqkv (+ PE parameter grads)
     t = _pe_tables(mode, grid, pe_param, inv_freq, degree, per_head)
     dpe = torch.zeros_like(pe_param) if pe_param is not None else None
     name = MODES[mode]
-    dqkv = K.fused_attention_bwd(xn.contiguous(), K.pack_qkv_weights(wqkv.contiguous(), dt, num_heads),
-                                 da.view(B, N, D), num_heads, t,
-                                 dtable=dpe if name == "relative" else None,
-                                 dcoeff=dpe if name == "polynomial" else None,
-                                 dfreqs=dpe if name == "rope-mixed" else None)
+    pe_grads = dict(dtable=dpe if name == "relative" else None, dcoeff=dpe if name == "polynomial" else None,
+                    dfreqs=dpe if name == "rope-mixed" else None)
+    if qkv.numel() == 0:
+        dqkv = K.fused_attention_bwd(xn.contiguous(), K.pack_qkv_weights(wqkv.contiguous(), dt, num_heads),
+                                     da.view(B, N, D), num_heads, t, **pe_grads)
+    else:
+        dqkv = K.attention_core_bwd(qkv, da.view(B, N, D), num_heads, t, **pe_grads)
     dq2 = dqkv.view(B * N, 3 * D)
     dxn = K.linear(dq2, _shadow_t(wqkv, dt), None, epi=L.EPI_BIAS).view(B, N, D)
     dwqkv = torch.zeros_like(wqkv)

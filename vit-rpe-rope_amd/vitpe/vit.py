@@ -75,7 +75,7 @@ class Attention(nn.Module):
         # the fused kernel regenerates them on the device from the module's own parameters.
         mode, pe_param, inv_freq, degree, per_head = _pe_args(self.pos_encoding, freqs_cis is not None)
         grid = int(math.sqrt(N - 1))
-        y, _ = torch.ops.vitpe.attention(x, self.qkv.weight, self.proj.weight, self.proj.bias, resid, self.num_heads,
+        y, _, _ = torch.ops.vitpe.attention(x, self.qkv.weight, self.proj.weight, self.proj.bias, resid, self.num_heads,
                                          mode, grid, pe_param, inv_freq, degree, per_head)
         return y
 
