@@ -138,6 +138,21 @@ int vitpe_linear_lnbwd(int dtype, const void* dY, const void* Wt, void* dx, cons
 int vitpe_gemm_tn(int dtype, const void* dY, const void* X, float* dW, float* dbias, int M, int N,
                   int K, int splits, vitpe_stream_t stream);
 
+/* vitpe_wgrad_group: the same product for a LIST of independent problems (<= 32) in one launch --
+ * e.g. every nn.Linear weight/bias gradient of the model (autograd's addmm backward in the
+ * reference: vit.py:35,37 and timm Mlp fc1/fc2, once per block).  `problems` is a HOST array; the
+ * descriptors travel as kernel arguments (no device table, graph-capture safe).  Work is cut into
+ * (192x192 output block, 64-token stage) units spread evenly over the CUs, so each output block is
+ * accumulated (fp32 atomics) by only a handful of workgroups.  N, K multiples of 8 (bf16) / 4 (fp32). */
+typedef struct {
+  const void* dY; /* [M,N] T */
+  const void* X;  /* [M,K] T */
+  float* dW;      /* [N,K] fp32, accumulated into */
+  float* dbias;   /* [N] fp32 or NULL, accumulated into */
+  int M, N, K, reserved;
+} vitpe_wgrad_problem;
+int vitpe_wgrad_group(int dtype, const vitpe_wgrad_problem* problems, int nprob, vitpe_stream_t stream);
+
 /* ---- LayerNorm (nn.LayerNorm(d), eps 1e-5: vit.py:113,116,210) ------------------------------ */
 /* y == NULL: row statistics only (mean and rstd required) */
 int vitpe_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y,

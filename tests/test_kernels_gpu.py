@@ -182,6 +182,54 @@ def test_gemm_tn_wgrad(K, dt, M, N, K_, splits):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_wgrad_group_many_problems_one_launch(K, dt):
+    """Ragged problem list (block edges, M not a multiple of the stage, with / without bias, repeated
+    launches accumulate): every problem against dY^T X on the values the kernel sees."""
+    shapes = [(650, 576, 192, True), (650, 192, 192, True), (333, 768, 192, True), (333, 192, 768, True),
+              (195, 96, 96, False), (260, 192, 48, True), (70, 200, 392, True), (1, 8, 8, True)]
+    probs, refs = [], []
+    for i, (M, N, K_, bias) in enumerate(shapes):
+        dy, x = rnd(M, N, seed=10 + i), rnd(M, K_, seed=40 + i)
+        dw = torch.zeros(N, K_, device="cuda")
+        db = torch.zeros(N, device="cuda") if bias else None
+        probs.append((dev(dy, DT[dt]), dev(x, DT[dt]), dw, db))
+        refs.append((q(dy, dt).t() @ q(x, dt), q(dy, dt).sum(0)))
+    grp = K.WgradGroup(probs)
+    grp.launch()
+    for (dy, x, dw, db), (rw, rb) in zip(probs, refs):
+        assert rel_err(dw.cpu(), rw) < tol(dt), tuple(dw.shape)
+        if db is not None:
+            assert rel_err(db.cpu(), rb) < tol(dt), tuple(dw.shape)
+    grp.launch()   # accumulates
+    for (dy, x, dw, db), (rw, rb) in zip(probs, refs):
+        assert rel_err(dw.cpu(), 2 * rw) < tol(dt)
+
+
+def test_wgrad_group_large_balanced_run(K):
+    """bench-like sizes (many stages per block, work runs crossing block and problem boundaries)"""
+    M = 65 * 96
+    probs, refs = [], []
+    for i, (N, K_) in enumerate([(576, 192), (192, 192), (768, 192), (192, 768)] * 2):
+        dy, x = rnd(M, N, seed=70 + i), rnd(M, K_, seed=90 + i)
+        dw, db = torch.zeros(N, K_, device="cuda"), torch.zeros(N, device="cuda")
+        probs.append((dev(dy, torch.bfloat16), dev(x, torch.bfloat16), dw, db))
+        refs.append((q(dy, "bf16").t() @ q(x, "bf16"), q(dy, "bf16").sum(0)))
+    K.wgrad_group(probs)
+    for (dy, x, dw, db), (rw, rb) in zip(probs, refs):
+        assert rel_err(dw.cpu(), rw) < 1e-4     # bf16 products are exact in fp32; only the summation order differs
+        assert rel_err(db.cpu(), rb) < 1e-4
+
+
+def test_wgrad_group_rejects_bad_lists(K):
+    from vitpe._lib import VitpeError
+    with pytest.raises(VitpeError):
+        K.WgradGroup([])
+    dy, x = torch.zeros(8, 8, device="cuda"), torch.zeros(8, 8, device="cuda")
+    with pytest.raises(VitpeError):
+        K.WgradGroup([(dy, x, torch.zeros(8, 8, device="cuda"), None)] * 33)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("M,D", [(195, 192), (67, 96), (33, 768)])
 def test_layernorm_fwd_bwd(K, dt, M, D):
     x, g, b = rnd(M, D, seed=1, scale=2.0) + 0.3, 1 + 0.1 * rnd(D, seed=2), 0.1 * rnd(D, seed=3)

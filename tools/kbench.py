@@ -95,6 +95,18 @@ def main():
     rec("gemm_tn dWqkv[576,192]", timeit(lambda: K.gemm_tn(dq2, x2, dwq, None)), 2 * M * D * 3 * D)
     dwp = torch.zeros(D, D, device=dev)
     rec("gemm_tn dWproj[192,192]", timeit(lambda: K.gemm_tn(y, x2, dwp, db2)), 2 * M * D * D)
+    grp1 = K.WgradGroup([(h, x2, dw1, db1), (y, h, dw2, db2), (dq2, x2, dwq, None), (y, x2, dwp, db2)])
+    fl_layer = 2 * M * (hid * D * 2 + 3 * D * D + D * D)
+    rec("wgrad_group 1 layer (4 GEMMs)", timeit(lambda: grp1.launch()), fl_layer)
+    probs6 = []
+    for _ in range(6):  # distinct operands and outputs per layer, as in the train step
+        z = torch.zeros
+        probs6 += [(r(M, hid), r(M, D), z(hid, D, device=dev), z(hid, device=dev)),
+                   (r(M, D), r(M, hid), z(D, hid, device=dev), z(D, device=dev)),
+                   (r(M, 3 * D), r(M, D), z(3 * D, D, device=dev), None),
+                   (r(M, D), r(M, D), z(D, D, device=dev), z(D, device=dev))]
+    grp6 = K.WgradGroup(probs6)
+    rec("wgrad_group 6 layers (24 GEMMs)", timeit(lambda: grp6.launch()), 6 * fl_layer)
     g, bt = torch.ones(D, device=dev), torch.zeros(D, device=dev)
     x3 = x2.view(B, N, D)
     yy, mean, rstd = K.layernorm_fwd(x3, g, bt)

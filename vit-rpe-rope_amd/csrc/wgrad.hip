@@ -1,0 +1,258 @@
+// Grouped weight-gradient GEMMs:  dW_p[n][k] += sum_m dY_p[m][n] X_p[m][k]   (+ dbias_p[n] += sum_m dY_p[m][n])
+// for a whole list of problems p in ONE launch (the reference gets these from autograd's addmm
+// backward, one ATen call per nn.Linear: vit.py:35,37, timm Mlp fc1/fc2).
+//
+// Why grouped: a ViT-tiny weight gradient has a tiny output (192x192 .. 768x192) and a huge
+// contraction (M = batch x tokens = 33 280 rows), so every workgroup that shares an output block
+// must add its partial result with fp32 atomics, and the atomics' traffic is (#workgroups per
+// block) x (output bytes).  One launch per GEMM needs ~20-60 slices per block to fill 256 CUs;
+// all 24 GEMMs of the model in one launch need ~3.5.  The activations / gradients stay resident
+// (288 GB of HBM), so nothing forces the weight gradients to run inside the backward chain.
+//
+// Work decomposition ("stream-K"): the unit of work is (output block of 192x192, stage of RPS
+// token rows).  All units of all problems form one sequence, cut into equal contiguous runs, one
+// per workgroup (= one per CU): perfect balance, and a workgroup flushes at most two partial blocks.
+//
+// Block 192 (dY columns) x 192 (X columns), 12 waves as 4 x 3, wave tile 48 x 64 (12 MFMAs per
+// 7 transposed operand fragments and K32 chunk).  A stage is staged row-major as it lies in HBM
+// (16-B coalesced loads, register prefetch one stage ahead, double-buffered LDS, one barrier per
+// stage) and consumed through transposed LDS reads (ds_read_b64_tr_b16).  bf16 rows are 384 B
+// (no padding); the 32-B pieces of a row are XOR-swizzled so that the 16 row-pieces one transposed
+// read touches per 32 lanes cover all 64 banks exactly once.
+#include "common.h"
+
+namespace vitpe {
+
+constexpr int WG_MAXPROB = 32;
+constexpr int WG_BLK = 192;
+
+struct WgProb {
+  const void* dY;  // [M,N] T
+  const void* X;   // [M,K] T
+  float* dW;       // [N,K] fp32, accumulated into
+  float* dbias;    // [N] fp32 or null, accumulated into
+  int M, N, K;
+  int unit0;       // index of this problem's first work unit
+  int nbn;         // 192-wide blocks along N
+  int stages;      // ceil(M / RPS)
+};
+struct WgArgs {
+  int nprob, total_units, units_per_wg, pad;
+  WgProb p[WG_MAXPROB];
+};
+
+template <typename T> struct WgLayout;
+template <> struct WgLayout<bf16> {
+  static constexpr int LD = WG_BLK;
+  // element offset of 16-B chunk cc (8 elements) of row r: 32-B pieces swizzled within groups of four
+  static __device__ __forceinline__ int chunk(int r, int cc) {
+    const int s = ((r >> 1) & 1) | (((r >> 3) & 1) << 1);
+    return r * LD + ((((cc >> 1) ^ s)) << 4) + ((cc & 1) << 3);
+  }
+  // transposed fragment: rows rb0..rb0+3 / rb1..rb1+3 (rb multiple of 4), 16 columns at c0 (multiple of 16)
+  static __device__ __forceinline__ Frag<bf16> tr(const bf16* tile, int rb0, int rb1, int c0) {
+    const int i = threadIdx.x & 15, q = i >> 2, p = i & 3;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int r0 = rb0 + q, r1 = rb1 + q;
+    const int s0 = ((r0 >> 1) & 1) | (((r0 >> 3) & 1) << 1), s1 = ((r1 >> 1) & 1) | (((r1 >> 3) & 1) << 1);
+    const bf16* a0 = tile + r0 * LD + (((c0 >> 4) ^ s0) << 4) + 4 * p;
+    const bf16* a1 = tile + r1 * LD + (((c0 >> 4) ^ s1) << 4) + 4 * p;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a1);
+    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    Frag<bf16> f;
+    f.v = __builtin_bit_cast(bf16x8, both);
+    return f;
+  }
+};
+template <> struct WgLayout<float> {  // exact-fp32 parity mode: padded rows, scalar column gathers
+  static constexpr int LD = WG_BLK + 4;
+  static __device__ __forceinline__ int chunk(int r, int cc) { return r * LD + cc * 4; }
+  static __device__ __forceinline__ Frag<float> tr(const float* tile, int rb0, int rb1, int c0) {
+    return ld_frag_tr(tile, LD, rb0, rb1, c0);
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
+  using LY = WgLayout<T>;
+  constexpr int RPS = 128 / (int)sizeof(T);  // token rows per stage: 64 bf16 / 32 fp32
+  constexpr int CPS = RPS / 32;              // K32 chunks per stage
+  constexpr int CHN = CH<T>::n;
+  constexpr int CPR = WG_BLK / CHN;          // 16-B chunks per slab row
+  static_assert(RPS * CPR == 2 * 768, "a slab is two chunks per thread");
+  constexpr int SLAB = RPS * LY::LD;
+  __shared__ __attribute__((aligned(16))) T sm[2 * 2 * SLAB];  // [buffer][Y | X][RPS][LD]
+
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave / 3, wk = wave % 3;
+
+  struct Cur {
+    const T* dY; const T* X; float* dW; float* dbias;
+    int M, N, K, n0, k0, stage, stages;
+  };
+  auto decode = [&](int u, Cur& s) {
+    int pi = 0;
+    for (int i = 1; i < a.nprob; ++i) pi = (u >= a.p[i].unit0) ? i : pi;
+    const WgProb& P = a.p[pi];
+    const int ub = u - P.unit0, blk = ub / P.stages;
+    s.dY = reinterpret_cast<const T*>(P.dY); s.X = reinterpret_cast<const T*>(P.X); s.dW = P.dW; s.dbias = P.dbias;
+    s.M = P.M; s.N = P.N; s.K = P.K; s.stages = P.stages;
+    s.stage = ub - blk * P.stages;
+    s.n0 = (blk % P.nbn) * WG_BLK;
+    s.k0 = (blk / P.nbn) * WG_BLK;
+  };
+
+  const Chunk16 zero = {0u, 0u, 0u, 0u};
+  Chunk16 rg[4];
+  auto gload = [&](const Cur& s) {
+    const int mb = s.stage * RPS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = tid + 768 * (i & 1), row = q / CPR, cc = q % CPR;
+      const int gm = mb + row;
+      if (i < 2) {
+        const int gn = s.n0 + cc * CHN;
+        rg[i] = (gm < s.M && gn < s.N) ? *reinterpret_cast<const Chunk16*>(s.dY + (size_t)gm * s.N + gn) : zero;
+      } else {
+        const int gk = s.k0 + cc * CHN;
+        rg[i] = (gm < s.M && gk < s.K) ? *reinterpret_cast<const Chunk16*>(s.X + (size_t)gm * s.K + gk) : zero;
+      }
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = tid + 768 * (i & 1), row = q / CPR, cc = q % CPR;
+      *reinterpret_cast<Chunk16*>(sm + (buf * 2 + (i >> 1)) * SLAB + LY::chunk(row, cc)) = rg[i];
+    }
+  };
+
+  f32x4 acc[3][4], accb[3];
+  auto clear = [&]() {
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+      accb[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) acc[nt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  Frag<T> ones;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) ones.v[t] = from_f32<T>(1.0f);
+
+  auto compute = [&](int buf, bool bias) {
+    const T* sY = sm + (buf * 2 + 0) * SLAB;
+    const T* sX = sm + (buf * 2 + 1) * SLAB;
+#pragma unroll
+    for (int cs = 0; cs < CPS; ++cs) {
+      const int rb0 = cs * 32 + 8 * g, rb1 = rb0 + 4;
+      Frag<T> fy[3], fx[4];
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) fy[nt] = LY::tr(sY, rb0, rb1, wn * 48 + 16 * nt);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) fx[kt] = LY::tr(sX, rb0, rb1, wk * 64 + 16 * kt);
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) mma(fy[nt], fx[kt], acc[nt][kt]);
+      if (bias) {  // column sums of dY on the matrix core: dY^T . 1
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) mma(fy[nt], ones, accb[nt]);
+      }
+    }
+  };
+  auto flush = [&](const Cur& s, bool bias) {
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gn = s.n0 + wn * 48 + 16 * nt + 4 * g + r;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          const int gk = s.k0 + wk * 64 + 16 * kt + c;
+          if (gn < s.N && gk < s.K) atomicAdd(s.dW + (size_t)gn * s.K + gk, acc[nt][kt][r]);
+        }
+        if (bias && c == 0 && gn < s.N) atomicAdd(s.dbias + gn, accb[nt][r]);
+      }
+    clear();
+  };
+
+  const int u0 = blockIdx.x * a.units_per_wg;
+  const int uend = min(a.total_units, u0 + a.units_per_wg);
+  if (u0 >= uend) return;
+  Cur cur, nxt;
+  decode(u0, cur);
+  gload(cur);
+  clear();
+  for (int u = u0; u < uend; ++u) {
+    const int buf = (u - u0) & 1;
+    sstore(buf);
+    nxt = cur;
+    bool flush_now = (u + 1 == uend);
+    if (u + 1 < uend) {
+      if (cur.stage + 1 < cur.stages) nxt.stage = cur.stage + 1;
+      else { decode(u + 1, nxt); flush_now = true; }
+      gload(nxt);  // in flight under this stage's MFMAs
+    }
+    __syncthreads();
+    const bool bias = (cur.dbias != nullptr) && cur.k0 == 0 && wk == 0;
+    compute(buf, bias);
+    if (flush_now) flush(cur, bias);
+    cur = nxt;
+  }
+}
+
+}  // namespace vitpe
+
+using namespace vitpe;
+
+struct vitpe_wgrad_problem_abi {  // mirrors include/vitpe.h: vitpe_wgrad_problem
+  const void* dY;
+  const void* X;
+  float* dW;
+  float* dbias;
+  int M, N, K, reserved;
+};
+
+static int wgrad_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    n = v;
+  }
+  return n;
+}
+
+extern "C" int vitpe_wgrad_group(int dtype, const void* problems, int nprob, hipStream_t stream) {
+  VITPE_REQUIRE(problems && nprob >= 0 && nprob <= WG_MAXPROB && (dtype == 0 || dtype == 1));
+  const vitpe_wgrad_problem_abi* pr = reinterpret_cast<const vitpe_wgrad_problem_abi*>(problems);
+  const int RPS = dtype == 1 ? 64 : 32, CHN = dtype == 1 ? 8 : 4;
+  WgArgs a{};
+  int units = 0, np = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const vitpe_wgrad_problem_abi& p = pr[i];
+    VITPE_REQUIRE(p.dY && p.X && p.dW && p.M >= 0 && p.N > 0 && p.K > 0 && p.N % CHN == 0 && p.K % CHN == 0);
+    if (p.M == 0) continue;
+    WgProb& q = a.p[np++];
+    q.dY = p.dY; q.X = p.X; q.dW = p.dW; q.dbias = p.dbias; q.M = p.M; q.N = p.N; q.K = p.K;
+    q.unit0 = units;
+    q.nbn = (p.N + WG_BLK - 1) / WG_BLK;
+    q.stages = (p.M + RPS - 1) / RPS;
+    const long long nu = (long long)q.nbn * ((p.K + WG_BLK - 1) / WG_BLK) * q.stages;
+    VITPE_REQUIRE(units + nu < (1LL << 30));
+    units += (int)nu;
+  }
+  if (units == 0) return 0;
+  a.nprob = np;
+  a.total_units = units;
+  const int wgs = units < wgrad_cu_count() ? units : wgrad_cu_count();
+  a.units_per_wg = (units + wgs - 1) / wgs;
+  const int grid = (units + a.units_per_wg - 1) / a.units_per_wg;
+  if (dtype == 1) hipLaunchKernelGGL(wgrad_group_kernel<bf16>, dim3(grid), dim3(768), 0, stream, a);
+  else hipLaunchKernelGGL(wgrad_group_kernel<float>, dim3(grid), dim3(768), 0, stream, a);
+  VITPE_CHECK_LAUNCH();
+}

@@ -184,6 +184,9 @@ class TrainEngine:
         self.dqkv, self.du = self.dqkv_l[0], self.du_l[0]          # (bench.py times the kernels on these)
         self.side = torch.cuda.Stream(device=dev)
         self.overlap_wgrad = __import__("os").environ.get("VITPE_OVERLAP_WGRAD", "0") == "1"
+        # weight gradients: one grouped launch per backward part (default) or one GEMM per nn.Linear
+        self.group_wgrad = __import__("os").environ.get("VITPE_GROUP_WGRAD", "1") == "1" and not self.overlap_wgrad
+        self._wg_groups = {}
         self.dpatch = e(B * self.P, D)
         self.ln_ws = K.layernorm_bwd_workspace(M, D, dev)
         # positional-encoding operands of the fused attention kernels
@@ -253,8 +256,40 @@ class TrainEngine:
         K.cross_entropy(self.logits, self.labels, grad_scale=1.0 / self.B, dlogits=self.dlogits, out2=self.out2)
         self.metric_acc.add_(self.out2)
 
+    def _wgrad_problems(self, lo, hi, with_embed):
+        """(dY, X, dW, dbias) of every nn.Linear weight gradient of layers lo..hi (+ the patch embedding)."""
+        mdl, D, M, G = self.model, self.D, self.M, self.Gr
+        probs = []
+        for l in range(hi, lo - 1, -1):
+            blk, a = mdl.blocks[l], self.act[l]
+            probs += [(self.dx_out[l + 1].view(M, D), a["h"], G(blk.mlp.fc2.weight), G(blk.mlp.fc2.bias)),
+                      (self.du_l[l], a["xn2"].view(M, D), G(blk.mlp.fc1.weight), G(blk.mlp.fc1.bias)),
+                      (self.dx_mid[l].view(M, D), a["a"].view(M, D), G(blk.attn.proj.weight), G(blk.attn.proj.bias)),
+                      (self.dqkv_l[l].view(M, 3 * D), a["xn1"].view(M, D), G(blk.attn.qkv.weight), None)]
+        if with_embed:
+            probs.append((self.dpatch, self.patches, G(mdl.patch_embed.weight).view(D, -1), G(mdl.patch_embed.bias)))
+        return probs
+
+    def _wgrad_group(self, part):
+        """All weight gradients of `part` in one grouped launch (csrc/wgrad.hip) after the data-gradient chain:
+        their operands sit in per-layer buffers, so nothing forces them into the chain, and one launch over
+        24+ problems needs ~10x fewer atomically-combined partial blocks than 24 launches."""
+        if part not in self._wg_groups:
+            hi, lo = self.Lyr - 1, 0
+            if part == "upper":
+                lo = self.split_layer
+            elif part == "lower":
+                hi = self.split_layer - 1
+            probs = self._wgrad_problems(lo, hi, part != "upper")
+            self._wg_groups[part] = [K.WgradGroup(probs[i:i + K.WgradGroup.MAX])
+                                     for i in range(0, len(probs), K.WgradGroup.MAX)]
+        for grp in self._wg_groups[part]:
+            grp.launch()
+
     def _wgrad(self, after_event, fn):
         """Run a weight-gradient GEMM on the side stream once `after_event` (its producer) has completed."""
+        if self.group_wgrad:
+            return
         if not self.overlap_wgrad:
             fn()
             return
@@ -317,7 +352,10 @@ class TrainEngine:
             if isinstance(mdl.pos_embed, AbsolutePositionalEncoding):
                 dape = G(mdl.pos_embed.pos_embed)[0, :self.P]
             K.embed_bwd(self.dx_out[0], G(mdl.cls_token).view(-1), dape, out=self.dpatch)
-            K.gemm_tn(self.dpatch, self.patches, G(mdl.patch_embed.weight).view(D, -1), G(mdl.patch_embed.bias))
+            if not self.group_wgrad:
+                K.gemm_tn(self.dpatch, self.patches, G(mdl.patch_embed.weight).view(D, -1), G(mdl.patch_embed.bias))
+        if self.group_wgrad:
+            self._wgrad_group(part)
         if self.overlap_wgrad:
             main.wait_stream(self.side)   # join: every gradient is complete before the all-reduce / optimizer
 

@@ -6,6 +6,7 @@ in Python; there is no fallback path.
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Optional, Tuple
 
 import torch
@@ -110,6 +111,42 @@ def gemm_tn(dy, x, dw, dbias=None, splits=None):
         splits = wgrad_splits(M, N, K)
     check(lib().vitpe_gemm_tn(dtype_code(dy.dtype), ptr(dy), ptr(x), ptr(dw), ptr(dbias), M, N, K, splits,
                               stream_ptr()), "vitpe_gemm_tn")
+
+
+class _WgradProblem(ctypes.Structure):   # include/vitpe.h: vitpe_wgrad_problem
+    _fields_ = [("dY", ctypes.c_void_p), ("X", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("dbias", ctypes.c_void_p),
+                ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+
+class WgradGroup:
+    """A fixed list of weight-gradient problems (dY [M,N], X [M,K], dW [N,K] fp32, dbias [N] fp32 | None),
+    launched together by one vitpe_wgrad_group call.  The tensors are referenced, not copied."""
+
+    MAX = 32
+
+    def __init__(self, problems):
+        problems = list(problems)
+        if not 0 < len(problems) <= self.MAX:
+            raise L.VitpeError(f"WgradGroup takes 1..{self.MAX} problems, got {len(problems)}")
+        self.keep = problems
+        self.dtype = problems[0][0].dtype
+        self.arr = (_WgradProblem * len(problems))()
+        for i, (dy, x, dw, db) in enumerate(problems):
+            require_device(dy, x, dw, db)
+            M, N = dy.shape
+            K = x.shape[1]
+            assert x.shape[0] == M and dw.numel() == N * K and dy.dtype == x.dtype == self.dtype
+            assert dy.is_contiguous() and x.is_contiguous() and dw.is_contiguous()
+            _f32(dw, "dw"), _f32(db, "dbias")
+            self.arr[i] = _WgradProblem(ptr(dy), ptr(x), ptr(dw), ptr(db), M, N, K, 0)
+
+    def launch(self):
+        check(lib().vitpe_wgrad_group(dtype_code(self.dtype), ctypes.addressof(self.arr), len(self.arr), stream_ptr()),
+              "vitpe_wgrad_group")
+
+
+def wgrad_group(problems):
+    WgradGroup(problems).launch()
 
 
 # ---- LayerNorm ------------------------------------------------------------------------------
