@@ -9,6 +9,7 @@
 // Both are written once over T in {bf16, float} (common.h): bf16 = 16x16x32 MFMA throughput
 // mode, float = exact fp32 16x16x4 MFMA for the 1e-4 parity gate.
 #include "common.h"
+#include <stdlib.h>
 
 namespace vitpe {
 
@@ -235,20 +236,26 @@ struct GemmPanelArgs {
   float* dbeta;
 };
 
-template <typename T, int EPI, bool STATS, bool LNA>
-__global__ __launch_bounds__(768) void gemm_panel_kernel(GemmPanelArgs a) {
+// Two shapes of the same kernel (WR x WC waves, wave tile 48 rows x 192/WC columns):
+//   3 x 4 = 12 waves, tile 144 x 192, 86 KB of LDS: one workgroup per CU;
+//   2 x 3 =  6 waves, tile  96 x 192, 74 KB of LDS: an experiment (two workgroups per CU would let one's
+//   epilogue overlap the other's MFMA phase) that does not pay -- see panel_shape() below.
+template <typename T, int EPI, bool STATS, bool LNA, int WR, int WC>
+__global__ __launch_bounds__(64 * WR * WC) __attribute__((amdgpu_waves_per_eu(3)))
+void gemm_panel_kernel(GemmPanelArgs a) {
   constexpr bool ROWMAP = STATS || (EPI == EPI_LN_BWD);   // 32 lanes per output row in the epilogue
-  constexpr int BM = 144, BN = 192, ROWB = 128;
+  constexpr int NTHR = 64 * WR * WC;
+  constexpr int BM = 48 * WR, BN = 192, ROWB = 128;
+  constexpr int NTW = BN / 16 / WC;                       // 16-column tiles per wave: 3 (WC = 4) or 4 (WC = 3)
   constexpr int BK = ROWB / (int)sizeof(T), CPS = BK / 32, CHN = CH<T>::n;
-  constexpr int STAGE = (BM + BN) * ROWB;                 // 43008 B
+  constexpr int STAGE = (BM + BN) * ROWB;                 // 43008 B (144 rows) / 36864 B (96 rows)
   constexpr int NCH = (BM + BN) * 8;                      // 16-B chunks per stage
-  constexpr int NIT = (NCH + 767) / 768;                  // 4
+  constexpr int NIT = (NCH + NTHR - 1) / NTHR;            // 4 / 6
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
-  __shared__ float s_red[BM * 4];
 
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / WC, wn = wave % WC;
   const int M = a.M, N = a.N, K = a.K;
   const int ntn = N / BN;  // column tiles, all done by this workgroup (persistent over the row panel)
   const int panel = blockIdx.x;
@@ -257,9 +264,9 @@ __global__ __launch_bounds__(768) void gemm_panel_kernel(GemmPanelArgs a) {
   const T* __restrict__ W = reinterpret_cast<const T*>(a.W);
   const Chunk16 zero = {0u, 0u, 0u, 0u};
 
-  f32x4 acc[3][3];  // [nt][mt]
+  f32x4 acc[NTW][3];  // [nt][mt]
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < NTW; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(768) void gemm_panel_kernel(GemmPanelArgs a) {
     const int n0 = (st / nk) * BN, k0 = (st % nk) * BK;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int q = tid + 768 * i, row = q >> 3, cc = q & 7;
+      const int q = tid + NTHR * i, row = q >> 3, cc = q & 7;
       const int kk = k0 + cc * CHN;
       Chunk16 v = zero;
       if (q < NCH && kk < K) {
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(768) void gemm_panel_kernel(GemmPanelArgs a) {
     unsigned char* base = smem + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int q = tid + 768 * i, row = q >> 3, cc = q & 7;
+      const int q = tid + NTHR * i, row = q >> 3, cc = q & 7;
       if (q < NCH) *reinterpret_cast<Chunk16*>(base + row * ROWB + ((cc ^ ((row >> 1) & 7)) << 4)) = r[i];
     }
   };
@@ -312,11 +319,11 @@ __global__ __launch_bounds__(768) void gemm_panel_kernel(GemmPanelArgs a) {
     const unsigned char* sW = sA + BM * ROWB;
 #pragma unroll
     for (int cs = 0; cs < CPS; ++cs) {
-      Frag<T> fw[3], fa[3];
+      Frag<T> fw[NTW], fa[3];
       // element offset 32cs + 8g  ->  16-B slot(s): bf16 slot = 4cs + g ; fp32 slots = 2g, 2g+1 (cs = 0)
 #pragma unroll
-      for (int nt = 0; nt < 3; ++nt) {
-        const int row = wn * 48 + 16 * nt + c;
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int row = wn * (16 * NTW) + 16 * nt + c;
         const unsigned char* rp = sW + row * ROWB;
         const int sw = (row >> 1) & 7;
         if (sizeof(T) == 2) {
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(768) void gemm_panel_kernel(GemmPanelArgs a) {
         }
       }
 #pragma unroll
-      for (int nt = 0; nt < 3; ++nt)
+      for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt) mma(fw[nt], fa[mt], acc[nt][mt]);
     }
@@ -351,7 +358,10 @@ __global__ __launch_bounds__(768) void gemm_panel_kernel(GemmPanelArgs a) {
   // waves park their fp32 accumulators in the (now idle) stage buffers, then all 768 threads apply
   // bias / residual / GELU on 8-column pieces with 16-byte coalesced loads and stores.
   constexpr int EP_LD = BN + 4;                      // fp32 row stride of the parked tile
-  static_assert(48 * EP_LD * 4 <= 2 * STAGE, "parked tile must fit");
+  constexpr int RP = 16 * WR;                        // rows parked per pass
+  constexpr int RPI = NTHR / 32;                     // ROWMAP: rows per iteration
+  constexpr int EI = ROWMAP ? (RP + RPI - 1) / RPI : (RP * 24 + NTHR - 1) / NTHR;
+  static_assert(RP * EP_LD * 4 <= 2 * STAGE, "parked tile must fit");
   float* ep = reinterpret_cast<float*>(smem);
   auto epilogue = [&](int n0) {
     const float invN = 1.0f / (float)BN;
@@ -367,15 +377,15 @@ __global__ __launch_bounds__(768) void gemm_panel_kernel(GemmPanelArgs a) {
                                                      // runtime `pass` sends the accumulators to scratch, measured 2x)
       __syncthreads();                               // stage buffers / previous pass fully consumed
 #pragma unroll
-      for (int nt = 0; nt < 3; ++nt)
-        *reinterpret_cast<f32x4*>(ep + (16 * wm + c) * EP_LD + wn * 48 + 16 * nt + 4 * g) = acc[nt][pass];
+      for (int nt = 0; nt < NTW; ++nt)
+        *reinterpret_cast<f32x4*>(ep + (16 * wm + c) * EP_LD + wn * (16 * NTW) + 16 * nt + 4 * g) = acc[nt][pass];
       __syncthreads();
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int qd = tid + 768 * i;
-        const int row = ROWMAP ? (tid >> 5) + 24 * i : qd / 24;   // parked row: wave-row row/16, c = row%16
+#pragma unroll ((EPI == EPI_LN_BWD || (STATS && EI > 2)) ? 1 : EI)  // rolled where the iterations' temporaries would overlap and spill
+      for (int i = 0; i < EI; ++i) {
+        const int qd = tid + NTHR * i;
+        const int row = ROWMAP ? (tid >> 5) + RPI * i : qd / 24;   // parked row: wave-row row/16, c = row%16
         const int pc = ROWMAP ? (tid & 31) : qd % 24;
-        const bool live = ROWMAP ? (pc < 24) : (qd < 48 * 24);
+        const bool live = ROWMAP ? (pc < 24 && row < RP) : (qd < RP * 24);
         const int gm = m0 + (row >> 4) * 48 + 16 * pass + (row & 15), gn = n0 + pc * 8;
         const bool ok = live && (gm < m_end);
         float v[8];
@@ -494,7 +504,7 @@ __global__ __launch_bounds__(768) void gemm_panel_kernel(GemmPanelArgs a) {
       // thread (row-group tid>>5, piece pc = tid&31) holds sums for columns 8pc..8pc+7: reduce the 24 row
       // groups through LDS (the stage buffers are idle), then one atomic per column and workgroup
       __syncthreads();
-      float* red = reinterpret_cast<float*>(smem);   // [24][2][192]
+      float* red = reinterpret_cast<float*>(smem);   // [RPI][2][192]
       const int pc = tid & 31, grp = tid >> 5;
       if (pc < 24) {
 #pragma unroll
@@ -508,33 +518,47 @@ __global__ __launch_bounds__(768) void gemm_panel_kernel(GemmPanelArgs a) {
         const int which = tid / BN, col = tid % BN;
         float sres = 0.f;
 #pragma unroll
-        for (int k = 0; k < 24; ++k) sres += red[(k * 2 + which) * BN + col];
+        for (int k = 0; k < RPI; ++k) sres += red[(k * 2 + which) * BN + col];
         atomicAdd((which == 0 ? a.dgamma : a.dbeta) + col, sres);
       }
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < NTW; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   };
 
-  // flattened stage loop, register prefetch two stages ahead ACROSS column-tile boundaries: the
-  // first slabs of the next tile are in flight while the current tile's epilogue stores drain
-  Chunk16 ra[NIT], rb[NIT];
-  gload(ra, 0);
-  if (S > 1) gload(rb, 1);
-  for (int st = 0; st < S; st += 2) {
-    sstore(ra, 0);
-    if (st + 2 < S) gload(ra, st + 2);
-    __syncthreads();
-    compute(0);
-    if (st % nk == nk - 1) epilogue((st / nk) * BN);
-    if (st + 1 < S) {
-      sstore(rb, 1);
-      if (st + 3 < S) gload(rb, st + 3);
+  // flattened stage loop, register prefetch ACROSS column-tile boundaries: the first slab(s) of the next
+  // tile are in flight while the current tile's epilogue stores drain.  One workgroup per CU: two stages
+  // ahead (two register sets); two workgroups per CU: one stage ahead (the co-resident workgroup covers
+  // the rest, and the second register set would not fit the 168-VGPR budget of 3 waves per SIMD).
+  if (WR * WC > 6) {
+    Chunk16 ra[NIT], rb[NIT];
+    gload(ra, 0);
+    if (S > 1) gload(rb, 1);
+    for (int st = 0; st < S; st += 2) {
+      sstore(ra, 0);
+      if (st + 2 < S) gload(ra, st + 2);
       __syncthreads();
-      compute(1);
-      if ((st + 1) % nk == nk - 1) epilogue(((st + 1) / nk) * BN);
+      compute(0);
+      if (st % nk == nk - 1) epilogue((st / nk) * BN);
+      if (st + 1 < S) {
+        sstore(rb, 1);
+        if (st + 3 < S) gload(rb, st + 3);
+        __syncthreads();
+        compute(1);
+        if ((st + 1) % nk == nk - 1) epilogue(((st + 1) / nk) * BN);
+      }
+    }
+  } else {
+    Chunk16 ra[NIT];
+    gload(ra, 0);
+    for (int st = 0; st < S; ++st) {
+      sstore(ra, st & 1);
+      if (st + 1 < S) gload(ra, st + 1);
+      __syncthreads();
+      compute(st & 1);
+      if (st % nk == nk - 1) epilogue((st / nk) * BN);
     }
   }
 }
@@ -703,44 +727,67 @@ extern "C" int vitpe_gemm_nt(int dtype, int epi, const void* A, const void* W, v
   return dtype == 1 ? launch_gemm_nt<bf16>(epi, a, stream) : launch_gemm_nt<float>(epi, a, stream);
 }
 
-// panel rows: as many panels as a multiple of the CU count, each <= 144 rows (9 MFMA row tiles)
-static int panel_rows_for(int M) {
-  const int waves = (M + 256 * 144 - 1) / (256 * 144);
-  const int npanels = 256 * waves;
+// panel rows: as many panels as a multiple of the workgroup slots (CUs x resident workgroups per CU), each at
+// most `bm` rows
+static int panel_rows_for(int M, int bm, int slots) {
+  const int waves = (M + slots * bm - 1) / (slots * bm);
+  const int npanels = slots * waves;
   int rows = (M + npanels - 1) / npanels;
   return rows < 16 ? 16 : rows;
 }
 
-template <typename T>
-static int launch_gemm_panel(int epi, GemmPanelArgs a, hipStream_t s) {
-  a.panel_rows = panel_rows_for(a.M);
+// 1 (default): 3 x 4 waves, 144-row tiles, one workgroup per CU.  0 (VITPE_PANEL_SHAPE=0, A/B measurements
+// only): 2 x 3 waves, 96-row tiles -- meant to run two workgroups per CU, but its 74 KB of LDS is above the
+// 64 KB up to which two workgroups are co-resident on a CU (residency census), so it runs one
+// 6-wave workgroup per CU and is 1.5x SLOWER (fc1+GELU 58 vs 38 us).
+static int panel_shape() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("VITPE_PANEL_SHAPE");
+    v = (e != nullptr && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
+template <typename T, int WR, int WC>
+static int launch_gemm_panel_shape(int epi, GemmPanelArgs a, hipStream_t s) {
+  constexpr int WGS_PER_CU = (WR * WC <= 6) ? 2 : 1;
+  a.panel_rows = panel_rows_for(a.M, 48 * WR, 256 * WGS_PER_CU);
   const int npanels = (a.M + a.panel_rows - 1) / a.panel_rows;
-  dim3 grid(npanels), block(768);
+  dim3 grid(npanels), block(64 * WR * WC);
+#define VITPE_PANEL(EPI, ST, LN) hipLaunchKernelGGL((gemm_panel_kernel<T, EPI, ST, LN, WR, WC>), grid, block, 0, s, a)
   if (a.mean_out != nullptr) {
     switch (epi) {
-      case EPI_BIAS: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS, true, false>), grid, block, 0, s, a); break;
-      case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS_RESID, true, false>), grid, block, 0, s, a); break;
+      case EPI_BIAS: VITPE_PANEL(EPI_BIAS, true, false); break;
+      case EPI_BIAS_RESID: VITPE_PANEL(EPI_BIAS_RESID, true, false); break;
       default: return (int)hipErrorInvalidValue;
     }
     VITPE_CHECK_LAUNCH();
   }
   if (a.ln_gamma != nullptr && epi != EPI_LN_BWD) {   // LayerNorm fused into the A-operand staging
     switch (epi) {
-      case EPI_BIAS: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS, false, true>), grid, block, 0, s, a); break;
-      case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS_GELU, false, true>), grid, block, 0, s, a); break;
+      case EPI_BIAS: VITPE_PANEL(EPI_BIAS, false, true); break;
+      case EPI_BIAS_GELU: VITPE_PANEL(EPI_BIAS_GELU, false, true); break;
       default: return (int)hipErrorInvalidValue;
     }
     VITPE_CHECK_LAUNCH();
   }
   switch (epi) {
-    case EPI_BIAS: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS, false, false>), grid, block, 0, s, a); break;
-    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS_GELU, false, false>), grid, block, 0, s, a); break;
-    case EPI_BIAS_RESID: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_BIAS_RESID, false, false>), grid, block, 0, s, a); break;
-    case EPI_GELU_BWD: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_GELU_BWD, false, false>), grid, block, 0, s, a); break;
-    case EPI_LN_BWD: hipLaunchKernelGGL((gemm_panel_kernel<T, EPI_LN_BWD, false, false>), grid, block, 0, s, a); break;
+    case EPI_BIAS: VITPE_PANEL(EPI_BIAS, false, false); break;
+    case EPI_BIAS_GELU: VITPE_PANEL(EPI_BIAS_GELU, false, false); break;
+    case EPI_BIAS_RESID: VITPE_PANEL(EPI_BIAS_RESID, false, false); break;
+    case EPI_GELU_BWD: VITPE_PANEL(EPI_GELU_BWD, false, false); break;
+    case EPI_LN_BWD: VITPE_PANEL(EPI_LN_BWD, false, false); break;
     default: return (int)hipErrorInvalidValue;
   }
+#undef VITPE_PANEL
   VITPE_CHECK_LAUNCH();
+}
+
+template <typename T>
+static int launch_gemm_panel(int epi, GemmPanelArgs a, hipStream_t s) {
+  if (sizeof(T) == 2 && panel_shape() == 0) return launch_gemm_panel_shape<T, 2, 3>(epi, a, s);
+  return launch_gemm_panel_shape<T, 3, 4>(epi, a, s);
 }
 
 // C = epi(A W^T) like vitpe_gemm_nt (no EPI_PATCH), plus optional LayerNorm statistics of the output rows

@@ -42,12 +42,14 @@ class TrainEngine:
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.use_graph = use_graph
         m = model
-        # LayerNorm fused into the neighbouring kernels (needs the 192-wide panel GEMM).  fuse_ln: None/"fwd"
-        # = forward only (default: the fused LayerNorm-backward epilogue spills and is not faster than the
-        # stand-alone kernel yet), True = forward and backward, False = stand-alone LayerNorm kernels.
+        # LayerNorm fused into the neighbouring kernels (needs the 192-wide panel GEMM).  fuse_ln: None / True
+        # = forward and backward (default), "fwd" = forward only (stand-alone LayerNorm-backward kernel),
+        # False = stand-alone LayerNorm kernels everywhere.
         ok = m.embed_dim == 192
+        if fuse_ln is None and "VITPE_FUSE_LN" in __import__("os").environ:   # experiment switch: fwd | all | off
+            fuse_ln = {"fwd": "fwd", "all": True, "off": False}[__import__("os").environ["VITPE_FUSE_LN"]]
         self.fuse_ln = ok and fuse_ln is not False
-        self.fuse_ln_bwd = ok and fuse_ln is True
+        self.fuse_ln_bwd = ok and (fuse_ln is True or fuse_ln is None)
         self.D, self.H, self.Lyr = m.embed_dim, m.num_heads, len(m.blocks)
         self.p = m.patch_size
         self.C = m.patch_embed.weight.shape[1]
