@@ -66,7 +66,7 @@ VITPE_DEV void stage_tokens(const AttnArgs& a, int b, T* xs, T* hbuf, int hbuf_e
         }
         v[it] = f32_to_chunk<T>(f);
         if (a.xn_out != nullptr)
-          *reinterpret_cast<Chunk16*>(reinterpret_cast<T*>(a.xn_out) + ((size_t)b * N + row) * D + cc * CHN) = v[it];
+          __builtin_nontemporal_store(v[it], reinterpret_cast<Chunk16*>(reinterpret_cast<T*>(a.xn_out) + ((size_t)b * N + row) * D + cc * CHN));  // read again only in backward
       }
     }
   }

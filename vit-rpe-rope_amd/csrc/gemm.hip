@@ -296,7 +296,7 @@ void gemm_panel_kernel(GemmPanelArgs a) {
               }
               v = f32_to_chunk<T>(f);
               if (a.xn_out != nullptr && st < nk)   // first column tile only
-                *reinterpret_cast<Chunk16*>(reinterpret_cast<T*>(a.xn_out) + (size_t)(m0 + row) * K + kk) = v;
+                __builtin_nontemporal_store(v, reinterpret_cast<Chunk16*>(reinterpret_cast<T*>(a.xn_out) + (size_t)(m0 + row) * K + kk));
             }
           }
         } else {
@@ -460,7 +460,7 @@ void gemm_panel_kernel(GemmPanelArgs a) {
           if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
             for (int h = 0; h < 8 / CHN; ++h)
-              *reinterpret_cast<Chunk16*>(reinterpret_cast<T*>(a.U) + off + h * CHN) = f32_to_chunk<T>(v + h * CHN);
+              __builtin_nontemporal_store(f32_to_chunk<T>(v + h * CHN), reinterpret_cast<Chunk16*>(reinterpret_cast<T*>(a.U) + off + h * CHN));
 #pragma unroll
             for (int t = 0; t < 8; ++t) v[t] = gelu_erf(v[t]);
           }
