@@ -133,6 +133,18 @@ int vitpe_linear_ln(int dtype, int epi, const void* X, const float* gamma, const
 int vitpe_linear_lnbwd(int dtype, const void* dY, const void* Wt, void* dx, const void* x, const float* mean,
                        const float* rstd, const float* gamma, const void* dres, float* dgamma, float* dbeta,
                        int M, int K, vitpe_stream_t stream);
+/* vitpe_mlp_fwd: the whole MLP branch of a block in one kernel (vit.py:116-118,124 with timm Mlp):
+ *   xn = LayerNorm(x) ; u = xn W1^T + b1 ; h = gelu(u) ; out = x + h W2^T + b2
+ * x raw rows [M,192] with their LayerNorm statistics mean/rstd (e.g. vitpe_linear's stats output);
+ * xn_out (nullable), u_out, h_out [M,HID] are kept for the backward pass; mean_out/rstd_out (both or
+ * neither) receive the LayerNorm statistics of the OUTPUT rows.  bf16 (dtype 1), D == 192,
+ * HID % 192 == 0 (vitpe_mlp_fwd_supported); anything else returns hipErrorNotSupported -- run
+ * vitpe_linear_ln + vitpe_linear instead.                                                        */
+int vitpe_mlp_fwd_supported(int dtype, int D, int HID);
+int vitpe_mlp_fwd(int dtype, const void* x, const float* gamma, const float* beta, const float* mean,
+                  const float* rstd, void* xn_out, const void* W1, const float* b1, const void* W2,
+                  const float* b2, void* u_out, void* h_out, void* out, float* mean_out, float* rstd_out,
+                  float eps, int M, int D, int HID, vitpe_stream_t stream);
 /* vitpe_gemm_tn: dW[N,K] += dY[M,N]^T X[M,K] ; dbias[N] += colsum(dY) (NULL to skip).  fp32
  * outputs, accumulated with atomics over `splits` token slices.                             */
 int vitpe_gemm_tn(int dtype, const void* dY, const void* X, float* dW, float* dbias, int M, int N,

@@ -181,6 +181,50 @@ def test_gemm_tn_wgrad(K, dt, M, N, K_, splits):
     assert rel_err(dw.cpu(), 2 * ref_w) < tol(dt)
 
 
+@pytest.mark.parametrize("M,HID,with_stats", [(650, 768, True), (130 * 3 + 7, 768, False), (33, 384, True)])
+def test_fused_mlp_forward(K, M, HID, with_stats):
+    """x + fc2(gelu(fc1(LN(x)))) in one kernel (bf16) against (a) fp32 math on the bf16-rounded operands and
+    (b) the two-launch path (vitpe_linear_ln + vitpe_linear) it replaces."""
+    D = 192
+    bf = torch.bfloat16
+    x, g, b = rnd(M, D, seed=1), 1 + 0.1 * rnd(D, seed=2), 0.1 * rnd(D, seed=3)
+    w1, b1 = rnd(HID, D, seed=4, scale=0.08), 0.1 * rnd(HID, seed=5)
+    w2, b2 = rnd(D, HID, seed=6, scale=0.05), 0.1 * rnd(D, seed=7)
+    xq, w1q, w2q = q(x, "bf16"), q(w1, "bf16"), q(w2, "bf16")
+    xn = q(torch.nn.functional.layer_norm(xq, (D,), g, b), "bf16")
+    u_ref = xn @ w1q.t() + b1
+    h_ref = torch.nn.functional.gelu(u_ref)
+    out_ref = xq + q(h_ref, "bf16") @ w2q.t() + b2
+    xd = dev(x, bf)
+    _, mean, rstd = K.layernorm_fwd(xd, dev(g), dev(b))
+    xn_out = torch.empty_like(xd)
+    mo, ro = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    out, u, h = K.mlp_fwd(xd, dev(g), dev(b), mean, rstd, dev(w1, bf), dev(b1), dev(w2, bf), dev(b2), xn_out=xn_out,
+                          stats=(mo, ro) if with_stats else None)
+    assert rel_err(xn_out.float().cpu(), xn) < 1e-2
+    assert rel_err(u.float().cpu(), u_ref) < BF16_TOL
+    assert rel_err(h.float().cpu(), h_ref) < BF16_TOL
+    assert rel_err(out.float().cpu(), out_ref) < BF16_TOL
+    # the path it replaces: same operands, same rounding points -> (almost) the same bits
+    from vitpe import _lib as L
+    h2, u2 = K.linear_ln(xd, dev(g), dev(b), mean, rstd, dev(w1, bf), dev(b1), epi=L.EPI_BIAS_GELU)
+    out2 = K.linear(h2, dev(w2, bf), dev(b2), epi=L.EPI_BIAS_RESID, resid=xd)
+    assert rel_err(u.float().cpu(), u2.float().cpu()) < 1e-5
+    assert rel_err(h.float().cpu(), h2.float().cpu()) < 1e-5
+    assert rel_err(out.float().cpu(), out2.float().cpu()) < 2e-3
+    if with_stats:
+        o = out.float().cpu()
+        assert rel_err(mo.cpu(), o.mean(1)) < 1e-4
+        assert rel_err(ro.cpu(), 1 / torch.sqrt(o.var(1, unbiased=False) + 1e-5)) < 1e-4
+
+
+def test_fused_mlp_unsupported_is_an_error(K):
+    from vitpe._lib import VitpeError
+    z = lambda *s: torch.zeros(*s, device="cuda")  # noqa: E731
+    with pytest.raises(VitpeError):   # fp32: the images do not fit LDS, the caller must take the two-launch path
+        K.mlp_fwd(z(8, 192), z(192), z(192), z(8), z(8), z(768, 192), z(768), z(192, 768), z(192))
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_wgrad_group_many_problems_one_launch(K, dt):
     """Ragged problem list (block edges, M not a multiple of the stage, with / without bias, repeated

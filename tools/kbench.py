@@ -54,6 +54,9 @@ def main():
     rec("attn_fwd relative", timeit(lambda: K.fused_attention_fwd(xn, wqkv, H, per, out=out)), fl_attn)
     rec("attn_bwd relative", timeit(lambda: K.fused_attention_bwd(xn, wqkv, dout, H, per, dtable=dtab, out=dqkv)), 2 * fl_attn)
 
+    qkvb = r(B, N, 3 * D)
+    rec("attn_core_fwd rope-axial (qkv in)", timeit(lambda: K.attention_core_fwd(qkvb, H, pe, out=out)), fl_attn - 2 * B * N * D * 3 * D)
+    rec("attn_core_bwd rope-axial (qkv in)", timeit(lambda: K.attention_core_bwd(qkvb, dout, H, pe, out=dqkv)), 2 * (fl_attn - 2 * B * N * D * 3 * D))
     x2, w1, b1 = r(M, D), r(hid, D) * 0.1, torch.zeros(hid, device=dev)
     h, u = torch.empty(M, hid, device=dev, dtype=T), torch.empty(M, hid, device=dev, dtype=T)
     w2, b2 = r(D, hid) * 0.1, torch.zeros(D, device=dev)
@@ -83,6 +86,8 @@ def main():
     rec("stats only", timeit(lambda: K.layernorm_fwd(x2, gam, bet, mean=mean_, rstd=rstd_, stats_only=True)), 0, M * D * 2)
     xno = torch.empty_like(x2)
     rec("linear_ln fc1+gelu (+xn out)", timeit(lambda: K.linear_ln(x2, gam, bet, mean_, rstd_, w1, b1, epi=L.EPI_BIAS_GELU, u=u, out=h, xn_out=xno)), fl1)
+    mo_, ro_ = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    rec("mlp_fwd fused (LN+fc1+gelu+fc2+res)", timeit(lambda: K.mlp_fwd(x2, gam, bet, mean_, rstd_, w1, b1, w2, b2, xn_out=xno, u=u, h=h, out=y, stats=(mo_, ro_))), 2 * fl1)
     dgm, dbt2 = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
     rec("linear_lnbwd dgrad fc1 K=768", timeit(lambda: K.linear_lnbwd(h, w1t, x2, mean_, rstd_, gam, x2, dgm, dbt2, out=y)), fl1)
     rec("linear_lnbwd dgrad qkv K=576", timeit(lambda: K.linear_lnbwd(dq2, wqt, x2, mean_, rstd_, gam, x2, dgm, dbt2, out=y)), 2 * M * D * 3 * D)

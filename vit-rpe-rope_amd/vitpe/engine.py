@@ -50,6 +50,10 @@ class TrainEngine:
             fuse_ln = {"fwd": "fwd", "all": True, "off": False}[__import__("os").environ["VITPE_FUSE_LN"]]
         self.fuse_ln = ok and fuse_ln is not False
         self.fuse_ln_bwd = ok and (fuse_ln is True or fuse_ln is None)
+        # whole-MLP-branch forward kernel (bf16, d = 192 only; VITPE_FUSE_MLP=0 falls back to two panel GEMMs)
+        self.fuse_mlp = (self.fuse_ln and compute_dtype == torch.bfloat16
+                         and __import__("os").environ.get("VITPE_FUSE_MLP", "1") == "1"
+                         and K.mlp_fwd_supported(compute_dtype, m.embed_dim, m.blocks[0].mlp.fc1.out_features))
         self.D, self.H, self.Lyr = m.embed_dim, m.num_heads, len(m.blocks)
         self.p = m.patch_size
         self.C = m.patch_embed.weight.shape[1]
@@ -232,13 +236,19 @@ class TrainEngine:
                 K.linear(a["a"].view(M, D), self.Sh(blk.attn.proj.weight), blk.attn.proj.bias.data,
                          epi=L.EPI_BIAS_RESID, resid=xin.view(M, D), out=a["xmid"].view(M, D), stats=(a["m2"], a["r2"]),
                          eps=blk.norm2.eps)
+                nxt = (self.act[l + 1]["m1"], self.act[l + 1]["r1"]) if l + 1 < self.Lyr else None
+                eps_next = mdl.blocks[min(l + 1, self.Lyr - 1)].norm1.eps
+                if self.fuse_mlp:   # LN2 + fc1 + GELU + fc2 + residual (+ next LN1 statistics) in one kernel
+                    K.mlp_fwd(a["xmid"].view(M, D), blk.norm2.weight.data, blk.norm2.bias.data, a["m2"], a["r2"],
+                              self.Sh(blk.mlp.fc1.weight), blk.mlp.fc1.bias.data, self.Sh(blk.mlp.fc2.weight),
+                              blk.mlp.fc2.bias.data, xn_out=a["xn2"].view(M, D), u=a["u"], h=a["h"],
+                              out=self.x[l + 1].view(M, D), stats=nxt, eps=eps_next)
+                    continue
                 K.linear_ln(a["xmid"].view(M, D), blk.norm2.weight.data, blk.norm2.bias.data, a["m2"], a["r2"],
                             self.Sh(blk.mlp.fc1.weight), blk.mlp.fc1.bias.data, epi=L.EPI_BIAS_GELU, u=a["u"], out=a["h"],
                             xn_out=a["xn2"].view(M, D))
-                nxt = (self.act[l + 1]["m1"], self.act[l + 1]["r1"]) if l + 1 < self.Lyr else None
                 K.linear(a["h"], self.Sh(blk.mlp.fc2.weight), blk.mlp.fc2.bias.data, epi=L.EPI_BIAS_RESID,
-                         resid=a["xmid"].view(M, D), out=self.x[l + 1].view(M, D), stats=nxt,
-                         eps=mdl.blocks[min(l + 1, self.Lyr - 1)].norm1.eps)
+                         resid=a["xmid"].view(M, D), out=self.x[l + 1].view(M, D), stats=nxt, eps=eps_next)
                 continue
             K.layernorm_fwd(xin, blk.norm1.weight.data, blk.norm1.bias.data, blk.norm1.eps, out=a["xn1"],
                             mean=a["m1"], rstd=a["r1"])

@@ -113,6 +113,29 @@ def gemm_tn(dy, x, dw, dbias=None, splits=None):
                               stream_ptr()), "vitpe_gemm_tn")
 
 
+def mlp_fwd_supported(dtype, D, HID):
+    return bool(lib().vitpe_mlp_fwd_supported(dtype_code(dtype), D, HID))
+
+
+def mlp_fwd(x, gamma, beta, mean, rstd, w1, b1, w2, b2, xn_out=None, u=None, h=None, out=None, stats=None, eps=1e-5):
+    """Fused MLP branch: out = x + fc2(gelu(fc1(LayerNorm(x)))) on raw rows x [M,192] with their LayerNorm
+    statistics; returns (out, u, h).  stats=(mean_out, rstd_out) receives the statistics of the output rows."""
+    require_device(x, gamma, beta, mean, rstd, w1, b1, w2, b2, xn_out, u, h, out)
+    M, D = x.shape
+    HID = w1.shape[0]
+    assert w1.shape == (HID, D) and w2.shape == (D, HID) and x.dtype == w1.dtype == w2.dtype
+    _f32(gamma, "gamma"), _f32(beta, "beta"), _f32(b1, "b1"), _f32(b2, "b2")
+    u = u if u is not None else torch.empty((M, HID), dtype=x.dtype, device=x.device)
+    h = h if h is not None else torch.empty((M, HID), dtype=x.dtype, device=x.device)
+    out = out if out is not None else torch.empty_like(x)
+    mo, ro = stats if stats is not None else (None, None)
+    require_device(mo, ro)
+    check(lib().vitpe_mlp_fwd(dtype_code(x.dtype), ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(xn_out),
+                              ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(u), ptr(h), ptr(out), ptr(mo), ptr(ro), float(eps),
+                              M, D, HID, stream_ptr()), "vitpe_mlp_fwd")
+    return out, u, h
+
+
 class _WgradProblem(ctypes.Structure):   # include/vitpe.h: vitpe_wgrad_problem
     _fields_ = [("dY", ctypes.c_void_p), ("X", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("dbias", ctypes.c_void_p),
                 ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("reserved", ctypes.c_int)]
