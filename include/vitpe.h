@@ -145,6 +145,14 @@ int vitpe_mlp_fwd(int dtype, const void* x, const float* gamma, const float* bet
                   const float* rstd, void* xn_out, const void* W1, const float* b1, const void* W2,
                   const float* b2, void* u_out, void* h_out, void* out, float* mean_out, float* rstd_out,
                   float eps, int M, int D, int HID, vitpe_stream_t stream);
+/* vitpe_mlp_bwd: backward of that branch w.r.t. its input, same pipeline on the transposed weight shadows:
+ *   du = (dy fc2.weight) * gelu'(u)   [M,HID], stored (the fc1 weight gradient reads it)
+ *   dx = dy + LayerNorm'(du fc1.weight) ; dgamma / dbeta accumulated (fp32 atomics)
+ * W2t = fc2.weight^T [HID,192], W1t = fc1.weight^T [192,HID]; x = the LayerNorm's input rows with statistics
+ * mean / rstd and weight gamma.  (The reference gets all of this from autograd.)  Support as vitpe_mlp_fwd. */
+int vitpe_mlp_bwd(int dtype, const void* dy, const void* u, const void* W2t, const void* W1t, const void* x,
+                  const float* mean, const float* rstd, const float* gamma, void* du, void* dx, float* dgamma,
+                  float* dbeta, int M, int D, int HID, vitpe_stream_t stream);
 /* vitpe_gemm_tn: dW[N,K] += dY[M,N]^T X[M,K] ; dbias[N] += colsum(dY) (NULL to skip).  fp32
  * outputs, accumulated with atomics over `splits` token slices.                             */
 int vitpe_gemm_tn(int dtype, const void* dY, const void* X, float* dW, float* dbias, int M, int N,

@@ -218,6 +218,45 @@ def test_fused_mlp_forward(K, M, HID, with_stats):
         assert rel_err(ro.cpu(), 1 / torch.sqrt(o.var(1, unbiased=False) + 1e-5)) < 1e-4
 
 
+@pytest.mark.parametrize("M,HID", [(650, 768), (130 * 2 + 9, 768), (40, 384)])
+def test_fused_mlp_backward(K, M, HID):
+    """du, dx (incl. LayerNorm backward + residual), dgamma, dbeta of the fused kernel against autograd on the
+    bf16-rounded operands, and against the two-launch path it replaces."""
+    D, bf = 192, torch.bfloat16
+    from vitpe import _lib as L
+    x, g, b = rnd(M, D, seed=11), 1 + 0.1 * rnd(D, seed=12), 0.1 * rnd(D, seed=13)
+    w1, b1 = rnd(HID, D, seed=14, scale=0.08), 0.1 * rnd(HID, seed=15)
+    w2 = rnd(D, HID, seed=16, scale=0.05)
+    dy = rnd(M, D, seed=17)
+    # reference: fp32 autograd through LN -> fc1 -> gelu -> fc2 (+ residual path dy)
+    xr = q(x, "bf16").requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    xn = torch.nn.functional.layer_norm(xr, (D,), gr, br)
+    u_ref = xn @ q(w1, "bf16").t() + b1
+    y = xr + torch.nn.functional.gelu(u_ref) @ q(w2, "bf16").t()
+    y.backward(q(dy, "bf16"))
+    # device: forward for u and the statistics, then the fused backward
+    xd = dev(x, bf)
+    _, mean, rstd = K.layernorm_fwd(xd, dev(g), dev(b))
+    _, u, _ = K.mlp_fwd(xd, dev(g), dev(b), mean, rstd, dev(w1, bf), dev(b1), dev(w2, bf), torch.zeros(D, device="cuda"))
+    w2t, w1t = K.transpose_cast(dev(w2), bf), K.transpose_cast(dev(w1), bf)
+    dgam, dbet = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    dx, du = K.mlp_bwd(dev(dy, bf), u, w2t, w1t, xd, mean, rstd, dev(g), dgam, dbet)
+    du_ref = (q(dy, "bf16") @ q(w2, "bf16")) * (0.5 * (1 + torch.erf(u_ref / 2 ** 0.5))
+                                              + u_ref * torch.exp(-u_ref ** 2 / 2) / (2 * torch.pi) ** 0.5).detach()
+    assert rel_err(du.float().cpu(), du_ref) < BF16_TOL
+    assert rel_err(dx.float().cpu(), xr.grad) < BF16_TOL
+    assert rel_err(dgam.cpu(), gr.grad) < BF16_TOL
+    assert rel_err(dbet.cpu(), br.grad) < BF16_TOL
+    # the two launches it replaces
+    du2 = K.linear(dev(dy, bf), w2t, None, epi=L.EPI_GELU_BWD, u=u)
+    dg2, db2 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    dx2 = K.linear_lnbwd(du2, w1t, xd, mean, rstd, dev(g), dev(dy, bf), dg2, db2)
+    assert rel_err(du.float().cpu(), du2.float().cpu()) < 1e-5
+    assert rel_err(dx.float().cpu(), dx2.float().cpu()) < 2e-3
+    assert rel_err(dgam.cpu(), dg2.cpu()) < 1e-3 and rel_err(dbet.cpu(), db2.cpu()) < 1e-3
+
+
 def test_fused_mlp_unsupported_is_an_error(K):
     from vitpe._lib import VitpeError
     z = lambda *s: torch.zeros(*s, device="cuda")  # noqa: E731

@@ -88,6 +88,9 @@ def main():
     rec("linear_ln fc1+gelu (+xn out)", timeit(lambda: K.linear_ln(x2, gam, bet, mean_, rstd_, w1, b1, epi=L.EPI_BIAS_GELU, u=u, out=h, xn_out=xno)), fl1)
     mo_, ro_ = torch.empty(M, device=dev), torch.empty(M, device=dev)
     rec("mlp_fwd fused (LN+fc1+gelu+fc2+res)", timeit(lambda: K.mlp_fwd(x2, gam, bet, mean_, rstd_, w1, b1, w2, b2, xn_out=xno, u=u, h=h, out=y, stats=(mo_, ro_))), 2 * fl1)
+    dgm0, dbt0 = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    du_ = torch.empty_like(u)
+    rec("mlp_bwd fused (gelu' + dgrad + LN bwd)", timeit(lambda: K.mlp_bwd(x2, u, w2t, w1t, x2, mean_, rstd_, gam, dgm0, dbt0, du=du_, out=y)), 2 * fl1)
     dgm, dbt2 = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
     rec("linear_lnbwd dgrad fc1 K=768", timeit(lambda: K.linear_lnbwd(h, w1t, x2, mean_, rstd_, gam, x2, dgm, dbt2, out=y)), fl1)
     rec("linear_lnbwd dgrad qkv K=576", timeit(lambda: K.linear_lnbwd(dq2, wqt, x2, mean_, rstd_, gam, x2, dgm, dbt2, out=y)), 2 * M * D * 3 * D)

@@ -2,6 +2,9 @@
 // Mlp = fc1 -> GELU -> fc2), d = 192, bf16:
 //
 //   forward :  xn = LayerNorm2(x) ; u = xn W1^T + b1 ; h = gelu(u) ; out = x + h W2^T + b2   (+ LN stats of out)
+//   backward:  du = (dy W2) * gelu'(u) ; dxn = du W1 ; dx = dy + LayerNorm2'(dxn)  (+ dgamma, dbeta)
+//              -- the same two-GEMM pipeline on the transposed weight shadows: chunk j of du is stored once
+//              (the fc1 weight gradient reads it) and consumed from LDS; the residual is dy itself.
 //
 // One workgroup (12 waves, 3 x 4, wave tile 48 x 48) owns a panel of <= 144 token rows through BOTH
 // GEMMs.  The hidden activation is produced and consumed in chunks of 192 columns: chunk j of u comes
@@ -20,6 +23,11 @@
 
 namespace vitpe {
 
+enum { MLP_FWD = 0, MLP_BWD = 1 };
+
+// MLP_BWD reuses the fields: x = dy [M,192] (gradient of the block output), W1 = fc2.weight^T [HID,192],
+// W2 = fc1.weight^T [192,HID], u_out = du [M,HID] (output), out = dx [M,192]; gamma/mean/rstd = norm2's
+// weight and the statistics of its input rows ln_x; b1/b2/beta/xn_out/h_out/mean_out unused.
 struct MlpFwdArgs {
   const void* x;        // [M,192] raw block input of the MLP branch (x_mid)
   const float* gamma;   // norm2 weight / bias [192]
@@ -38,11 +46,15 @@ struct MlpFwdArgs {
   float* rstd_out;
   int M, HID, panel_rows;
   float eps;
+  const void* u_in;     // MLP_BWD: pre-activation u [M,HID] saved by the forward
+  const void* ln_x;     // MLP_BWD: LayerNorm input rows (x_mid) [M,192]
+  float* dgamma;        // MLP_BWD: accumulated (fp32 atomics, one per column and workgroup)
+  float* dbeta;
 };
 
 constexpr int MLP_D = 192, MLP_BM = 144, MLP_ROWB = 128;
 
-template <typename T>
+template <typename T, int MODE>
 __global__ __launch_bounds__(768) void mlp_fwd_kernel(MlpFwdArgs a) {
   static_assert(sizeof(T) == 2, "bf16 only: the fp32 images would not fit LDS (the engine's fp32 mode runs unfused)");
   constexpr int D = MLP_D, BM = MLP_BM, BN = 192, ROWB = MLP_ROWB, CHN = 8;
@@ -126,7 +138,7 @@ __global__ __launch_bounds__(768) void mlp_fwd_kernel(MlpFwdArgs a) {
     for (int it = 0; it < ITERS; ++it) {
       const int q = tid + 768 * it, row = q / 24, cc = q % 24;
       if (q < TOTAL) {
-        if (m0 + row < m_end) {
+        if (MODE == MLP_FWD && m0 + row < m_end) {
           const float mean = a.mean[m0 + row], rstd = a.rstd[m0 + row];
           float f[CHN];
           chunk_to_f32<T>(v[it], f);
@@ -190,18 +202,28 @@ __global__ __launch_bounds__(768) void mlp_fwd_kernel(MlpFwdArgs a) {
           const int gm = m0 + lrow, gn = j * BN + pc * 8;
           const f32x4 x0 = *reinterpret_cast<const f32x4*>(ep + row * EP_LD + pc * 8);
           const f32x4 x1 = *reinterpret_cast<const f32x4*>(ep + row * EP_LD + pc * 8 + 4);
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.b1 + gn);
-          const f32x4 b1v = *reinterpret_cast<const f32x4*>(a.b1 + gn + 4);
           float v[8];
+          Chunk16 hc;
+          if (MODE == MLP_FWD) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.b1 + gn);
+            const f32x4 b1v = *reinterpret_cast<const f32x4*>(a.b1 + gn + 4);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) { v[t] = x0[t] + b0[t]; v[4 + t] = x1[t] + b1v[t]; }
-          const Chunk16 uc = f32_to_chunk<T>(v);
+            for (int t = 0; t < 4; ++t) { v[t] = x0[t] + b0[t]; v[4 + t] = x1[t] + b1v[t]; }
+            const Chunk16 uc = f32_to_chunk<T>(v);
 #pragma unroll
-          for (int t = 0; t < 8; ++t) v[t] = gelu_erf(v[t]);
-          const Chunk16 hc = f32_to_chunk<T>(v);
-          if (gm < m_end) {
-            __builtin_nontemporal_store(uc, reinterpret_cast<Chunk16*>(Uo + (size_t)gm * HID + gn));
-            *reinterpret_cast<Chunk16*>(Ho + (size_t)gm * HID + gn) = hc;
+            for (int t = 0; t < 8; ++t) v[t] = gelu_erf(v[t]);
+            hc = f32_to_chunk<T>(v);
+            if (gm < m_end) {
+              __builtin_nontemporal_store(uc, reinterpret_cast<Chunk16*>(Uo + (size_t)gm * HID + gn));
+              *reinterpret_cast<Chunk16*>(Ho + (size_t)gm * HID + gn) = hc;
+            }
+          } else {   // du = (dy W2) * gelu'(u)
+            float uv[8];
+            chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(reinterpret_cast<const T*>(a.u_in) + (size_t)min(gm, m_end - 1) * HID + gn), uv);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { v[t] = x0[t] * gelu_erf_grad(uv[t]); v[4 + t] = x1[t] * gelu_erf_grad(uv[4 + t]); }
+            hc = f32_to_chunk<T>(v);
+            if (gm < m_end) *reinterpret_cast<Chunk16*>(Uo + (size_t)gm * HID + gn) = hc;
           }
           const int slab = pc >> 3, slot = pc & 7;
           *reinterpret_cast<Chunk16*>(sHB + slab * SLAB_A + lrow * ROWB + ((slot ^ ((lrow >> 1) & 7)) << 4)) = hc;
@@ -216,6 +238,91 @@ __global__ __launch_bounds__(768) void mlp_fwd_kernel(MlpFwdArgs a) {
     // ---- GEMM2: out += h_j W2[:, j]^T  (the step's barrier also orders the h image writes) ----------
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) step(6 * j + 3 + ks, sHB + ks * SLAB_A, acc2);
+  }
+
+  if (MODE == MLP_BWD) {
+    // ---- epilogue 2 (backward): tile = dxn, the gradient of the LayerNorm output.  dx = dy + rstd*(g - mean(g)
+    // - xhat*mean(g*xhat)), g = dxn*gamma, xhat = (x - mean)*rstd; dgamma += dxn*xhat, dbeta += dxn (column sums).
+    const float invN = 1.0f / (float)BN;
+    float lnacc_g[8], lnacc_b[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { lnacc_g[t] = 0.f; lnacc_b[t] = 0.f; }
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+      __syncthreads();
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt)
+        *reinterpret_cast<f32x4*>(ep + (16 * wm + c) * EP_LD + wn * 48 + 16 * nt + 4 * g) = acc2[nt][pass];
+      __syncthreads();
+#pragma unroll 1
+      for (int i = 0; i < 2; ++i) {   // 32 lanes per row (24 live): the row means reduce with shuffles
+        const int row = (tid >> 5) + 24 * i, pc = tid & 31;
+        const bool live = pc < 24;
+        const int gm = m0 + (row >> 4) * 48 + 16 * pass + (row & 15), gn = pc * 8;
+        const bool ok = live && gm < m_end;
+        const int gmc = min(gm, m_end - 1);
+        const size_t off = (size_t)gmc * D + gn;
+        const float mean = a.mean[gmc], rstd = a.rstd[gmc];
+        float v[8], xh[8], gv[8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { v[t] = 0.f; xh[t] = 0.f; gv[t] = 0.f; }
+        if (live) {
+          const f32x4 x0 = *reinterpret_cast<const f32x4*>(ep + row * EP_LD + pc * 8);
+          const f32x4 x1 = *reinterpret_cast<const f32x4*>(ep + row * EP_LD + pc * 8 + 4);
+          float xv[8];
+          chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(reinterpret_cast<const T*>(a.ln_x) + off), xv);
+          const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.gamma + gn);
+          const f32x4 g1 = *reinterpret_cast<const f32x4*>(a.gamma + gn + 4);
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            // the gradient as the unfused path sees it: dxn rounded to T
+            v[t] = to_f32(from_f32<T>(t < 4 ? x0[t & 3] : x1[t & 3]));
+            xh[t] = (xv[t] - mean) * rstd;
+            gv[t] = v[t] * (t < 4 ? g0[t & 3] : g1[t & 3]);
+            s1 += gv[t];
+            s2 += gv[t] * xh[t];
+          }
+        }
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        s1 *= invN;
+        s2 *= invN;
+        if (ok) {
+          float rv[8], o8[8];
+          chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(X + off), rv);   // residual gradient = dy itself
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            o8[t] = rstd * (gv[t] - s1 - xh[t] * s2) + rv[t];
+            lnacc_g[t] += v[t] * xh[t];
+            lnacc_b[t] += v[t];
+          }
+          *reinterpret_cast<Chunk16*>(Out + off) = f32_to_chunk<T>(o8);
+        }
+      }
+    }
+    // column sums: thread (row group tid>>5, piece tid&31) -> LDS [24][2][192] -> one atomic per column
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(sWB);
+    {
+      const int pc = tid & 31, grp = tid >> 5;
+      if (pc < 24) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          red[(grp * 2 + 0) * BN + pc * 8 + t] = lnacc_g[t];
+          red[(grp * 2 + 1) * BN + pc * 8 + t] = lnacc_b[t];
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, col = tid % BN;
+      float sres = 0.f;
+#pragma unroll
+      for (int k = 0; k < 24; ++k) sres += red[(k * 2 + which) * BN + col];
+      atomicAdd((which == 0 ? a.dgamma : a.dbeta) + col, sres);
+    }
+    return;
   }
 
   // ---- epilogue 2: + b2 + residual (the raw x rows), store, LayerNorm statistics of the output ----
@@ -276,6 +383,18 @@ __global__ __launch_bounds__(768) void mlp_fwd_kernel(MlpFwdArgs a) {
 
 using namespace vitpe;
 
+static int mlp_launch(int mode, MlpFwdArgs& a, hipStream_t stream) {
+  // as many panels as CUs (x waves of them), each <= 144 rows
+  const int waves = (a.M + 256 * MLP_BM - 1) / (256 * MLP_BM);
+  const int npanels = 256 * waves;
+  int rows = (a.M + npanels - 1) / npanels;
+  a.panel_rows = rows < 16 ? 16 : rows;
+  const int grid = (a.M + a.panel_rows - 1) / a.panel_rows;
+  if (mode == MLP_FWD) hipLaunchKernelGGL((mlp_fwd_kernel<bf16, MLP_FWD>), dim3(grid), dim3(768), 0, stream, a);
+  else hipLaunchKernelGGL((mlp_fwd_kernel<bf16, MLP_BWD>), dim3(grid), dim3(768), 0, stream, a);
+  VITPE_CHECK_LAUNCH();
+}
+
 extern "C" int vitpe_mlp_fwd_supported(int dtype, int D, int HID) {
   return dtype == 1 && D == MLP_D && HID > 0 && HID % 192 == 0;
 }
@@ -292,12 +411,21 @@ extern "C" int vitpe_mlp_fwd(int dtype, const void* x, const float* gamma, const
   a.x = x; a.gamma = gamma; a.beta = beta; a.mean = mean; a.rstd = rstd; a.xn_out = xn_out; a.W1 = W1; a.b1 = b1;
   a.W2 = W2; a.b2 = b2; a.u_out = u_out; a.h_out = h_out; a.out = out; a.mean_out = mean_out; a.rstd_out = rstd_out;
   a.M = M; a.HID = HID; a.eps = eps;
-  // as many panels as CUs (x waves of them), each <= 144 rows
-  const int waves = (M + 256 * MLP_BM - 1) / (256 * MLP_BM);
-  const int npanels = 256 * waves;
-  int rows = (M + npanels - 1) / npanels;
-  a.panel_rows = rows < 16 ? 16 : rows;
-  const int grid = (M + a.panel_rows - 1) / a.panel_rows;
-  hipLaunchKernelGGL(mlp_fwd_kernel<bf16>, dim3(grid), dim3(768), 0, stream, a);
-  VITPE_CHECK_LAUNCH();
+  return mlp_launch(MLP_FWD, a, stream);
+}
+
+// Backward of the MLP branch w.r.t. its input (the weight gradients are vitpe_wgrad_group problems on du / dy):
+//   du = (dy fc2.weight) * gelu'(u)  [M,HID] (stored) ; dx = dy + LayerNorm'(du fc1.weight) ; dgamma/dbeta accumulated.
+// W2t = fc2.weight^T [HID,192], W1t = fc1.weight^T [192,HID] (transposed shadows), x = LayerNorm input rows with
+// statistics mean/rstd.  Same support set as vitpe_mlp_fwd.
+extern "C" int vitpe_mlp_bwd(int dtype, const void* dy, const void* u, const void* W2t, const void* W1t, const void* x,
+                             const float* mean, const float* rstd, const float* gamma, void* du, void* dx,
+                             float* dgamma, float* dbeta, int M, int D, int HID, hipStream_t stream) {
+  VITPE_REQUIRE(dy && u && W2t && W1t && x && mean && rstd && gamma && du && dx && dgamma && dbeta && M >= 0);
+  if (!vitpe_mlp_fwd_supported(dtype, D, HID)) return (int)hipErrorNotSupported;
+  if (M == 0) return 0;
+  MlpFwdArgs a{};
+  a.x = dy; a.gamma = gamma; a.mean = mean; a.rstd = rstd; a.W1 = W2t; a.W2 = W1t; a.u_out = du; a.out = dx;
+  a.u_in = u; a.ln_x = x; a.dgamma = dgamma; a.dbeta = dbeta; a.M = M; a.HID = HID;
+  return mlp_launch(MLP_BWD, a, stream);
 }

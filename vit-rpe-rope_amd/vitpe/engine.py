@@ -332,16 +332,23 @@ class TrainEngine:
             e_dy = ev()
             # ---- MLP branch: x_out = xmid + fc2(gelu(fc1(LN2(xmid))))
             self._wgrad(e_dy, lambda: K.gemm_tn(dy, a["h"], G(blk.mlp.fc2.weight), G(blk.mlp.fc2.bias)))
-            K.linear(dy, self.St(blk.mlp.fc2.weight), None, epi=L.EPI_GELU_BWD, u=a["u"], out=du)
-            e_du = ev()
-            self._wgrad(e_du, lambda: K.gemm_tn(du, a["xn2"].view(M, D), G(blk.mlp.fc1.weight), G(blk.mlp.fc1.bias)))
-            if self.fuse_ln_bwd:   # data gradient of fc1 + LayerNorm2 backward + residual add in one kernel
-                K.linear_lnbwd(du, self.St(blk.mlp.fc1.weight), a["xmid"].view(M, D), a["m2"], a["r2"],
-                               blk.norm2.weight.data, dy, G(blk.norm2.weight), G(blk.norm2.bias), out=dmid3.view(M, D))
+            fc1_wgrad = lambda: K.gemm_tn(du, a["xn2"].view(M, D), G(blk.mlp.fc1.weight), G(blk.mlp.fc1.bias))  # noqa: E731
+            if self.fuse_mlp and self.fuse_ln_bwd:   # gelu' + both data gradients + LayerNorm2 backward + residual
+                K.mlp_bwd(dy, a["u"], self.St(blk.mlp.fc2.weight), self.St(blk.mlp.fc1.weight), a["xmid"].view(M, D),
+                          a["m2"], a["r2"], blk.norm2.weight.data, G(blk.norm2.weight), G(blk.norm2.bias), du=du,
+                          out=dmid3.view(M, D))
+                self._wgrad(ev(), fc1_wgrad)
             else:
-                K.linear(du, self.St(blk.mlp.fc1.weight), None, out=self.dtmp.view(M, D))
-                K.layernorm_bwd(self.dtmp, a["xmid"], a["m2"], a["r2"], blk.norm2.weight.data, G(blk.norm2.weight),
-                                G(blk.norm2.bias), dres=dy3, out=dmid3, workspace=self.ln_ws)
+                K.linear(dy, self.St(blk.mlp.fc2.weight), None, epi=L.EPI_GELU_BWD, u=a["u"], out=du)
+                self._wgrad(ev(), fc1_wgrad)
+                if self.fuse_ln_bwd:   # data gradient of fc1 + LayerNorm2 backward + residual add in one kernel
+                    K.linear_lnbwd(du, self.St(blk.mlp.fc1.weight), a["xmid"].view(M, D), a["m2"], a["r2"],
+                                   blk.norm2.weight.data, dy, G(blk.norm2.weight), G(blk.norm2.bias),
+                                   out=dmid3.view(M, D))
+                else:
+                    K.linear(du, self.St(blk.mlp.fc1.weight), None, out=self.dtmp.view(M, D))
+                    K.layernorm_bwd(self.dtmp, a["xmid"], a["m2"], a["r2"], blk.norm2.weight.data, G(blk.norm2.weight),
+                                    G(blk.norm2.bias), dres=dy3, out=dmid3, workspace=self.ln_ws)
             # ---- attention branch: xmid = x_in + proj(attn(LN1(x_in)))
             dm = dmid3.view(M, D)
             e_dm = ev()

@@ -136,6 +136,22 @@ def mlp_fwd(x, gamma, beta, mean, rstd, w1, b1, w2, b2, xn_out=None, u=None, h=N
     return out, u, h
 
 
+def mlp_bwd(dy, u, w2t, w1t, x, mean, rstd, gamma, dgamma, dbeta, du=None, out=None):
+    """Backward of mlp_fwd w.r.t. x: -> (dx, du); dgamma/dbeta accumulated.  w2t = fc2.weight^T [HID,192],
+    w1t = fc1.weight^T [192,HID]."""
+    require_device(dy, u, w2t, w1t, x, mean, rstd, gamma, dgamma, dbeta, du, out)
+    M, D = dy.shape
+    HID = u.shape[1]
+    assert w2t.shape == (HID, D) and w1t.shape == (D, HID) and dy.dtype == u.dtype == w2t.dtype == w1t.dtype == x.dtype
+    _f32(gamma, "gamma"), _f32(dgamma, "dgamma"), _f32(dbeta, "dbeta")
+    du = du if du is not None else torch.empty_like(u)
+    out = out if out is not None else torch.empty_like(dy)
+    check(lib().vitpe_mlp_bwd(dtype_code(dy.dtype), ptr(dy), ptr(u), ptr(w2t), ptr(w1t), ptr(x), ptr(mean), ptr(rstd),
+                              ptr(gamma), ptr(du), ptr(out), ptr(dgamma), ptr(dbeta), M, D, HID, stream_ptr()),
+          "vitpe_mlp_bwd")
+    return out, du
+
+
 class _WgradProblem(ctypes.Structure):   # include/vitpe.h: vitpe_wgrad_problem
     _fields_ = [("dY", ctypes.c_void_p), ("X", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("dbias", ctypes.c_void_p),
                 ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("reserved", ctypes.c_int)]
