@@ -25,6 +25,7 @@ for p in (REPO, os.path.join(REPO, "vit-rpe-rope_amd")):
         sys.path.insert(0, p)
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_GBS = 8000.0               # HBM3E (same guide)
 ATTN_FWD_FLOP_PER_IMG_LAYER = 17_621_760   # qkv + QK^T + AV, N=65 d=192 H=6, 2 flop/MAC
 ATTN_FWD_BYTES_PER_IMG_LAYER = 49_920      # bf16 x in + out (weights amortised)
 
@@ -73,12 +74,62 @@ def time_attention_kernel(eng, iters=100):
     return fwd_ms, bwd_ms
 
 
-def committed_pmc():
-    """HBM traffic / MFMA-busy of the roofline kernel from the committed rocprofv3 --pmc passes
+def time_other_kernels(eng, iters=50):
+    """Launch durations of the other heavy kernels of the step on the engine's own layer-0 operands (HIP events
+    on the launch stream): fused MLP forward / backward (HBM-bound) and the grouped weight-gradient launch (MFMA)."""
+    from vitpe import kernels as K
+    if not (eng.fuse_mlp and eng.fuse_ln_bwd and eng.group_wgrad):
+        return []
+    blk, a, M, D = eng.model.blocks[0], eng.act[0], eng.M, eng.D
+    G = eng.Gr
+
+    def timed(fn):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    hid = blk.mlp.fc1.out_features
+    t_f = timed(lambda: K.mlp_fwd(a["xmid"].view(M, D), blk.norm2.weight.data, blk.norm2.bias.data, a["m2"], a["r2"],
+                                  eng.Sh(blk.mlp.fc1.weight), blk.mlp.fc1.bias.data, eng.Sh(blk.mlp.fc2.weight),
+                                  blk.mlp.fc2.bias.data, xn_out=a["xn2"].view(M, D), u=a["u"], h=a["h"],
+                                  out=eng.x[1].view(M, D)))
+    t_b = timed(lambda: K.mlp_bwd(eng.dx_out[1].view(M, D), a["u"], eng.St(blk.mlp.fc2.weight), eng.St(blk.mlp.fc1.weight),
+                                  a["xmid"].view(M, D), a["m2"], a["r2"], blk.norm2.weight.data, G(blk.norm2.weight),
+                                  G(blk.norm2.bias), du=eng.du_l[0], out=eng.dx_mid[0].view(M, D)))
+    t_w = timed(lambda: eng._wgrad_group("all"))
+    eng.flat_g.zero_()
+    mlp_bytes = M * (3 * D + 2 * hid) * 2                  # x / dy in, xn / x in-out, out ; u and h (du) once each
+    mlp_flop = 2 * 2 * M * D * hid
+    wg_flop = sum(2 * dy.shape[0] * dy.shape[1] * x.shape[1] for grp in eng._wg_groups["all"] for dy, x, _, _ in grp.keep)
+    return [
+        {"kernel": "mlp_fwd_kernel (LN2+fc1+GELU+fc2+residual+stats, one layer)", "bound": "hbm", "launch_ms": round(t_f, 5),
+         "achieved": round(mlp_bytes / (t_f * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(mlp_bytes / (t_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": mlp_bytes,
+         "tflops": round(mlp_flop / (t_f * 1e-3) / 1e12, 1)},
+        {"kernel": "mlp_fwd_kernel<BWD> (gelu'+dgrad fc2/fc1+LN2 bwd+residual, one layer)", "bound": "hbm",
+         "launch_ms": round(t_b, 5), "achieved": round(mlp_bytes / (t_b * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+         "unit": "GB/s", "frac": round(mlp_bytes / (t_b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+         "algorithmic_bytes_per_launch": mlp_bytes, "tflops": round(mlp_flop / (t_b * 1e-3) / 1e12, 1)},
+        {"kernel": "wgrad_group_kernel (all nn.Linear weight gradients of the model, one launch)", "bound": "mfma",
+         "launch_ms": round(t_w, 5), "achieved": round(wg_flop / (t_w * 1e-3) / 1e12, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
+         "unit": "TFLOP/s", "frac": round(wg_flop / (t_w * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+         "algorithmic_flop_per_launch": wg_flop},
+    ]
+
+
+def committed_pmc(kernel="attn_fwd_kernel"):
+    """HBM traffic / MFMA-busy of a kernel from the committed rocprofv3 --pmc passes
     (tools/pmc_attn.py + tools/summarize_pmc.py -> profiles/r01_attn_fwd_pmc.json; same kernel, same shape)."""
     try:
         with open(os.path.join(REPO, "profiles", "r01_attn_fwd_pmc.json")) as f:
-            return json.load(f)["attn_fwd_kernel"]
+            return json.load(f)[kernel]
     except Exception:
         return None
 
@@ -155,6 +206,11 @@ def main():
     loss, _ = eng.read_metrics()
 
     fwd_ms, bwd_ms = time_attention_kernel(eng)
+    others = time_other_kernels(eng) if (rank == 0 and args.dtype == "bf16") else []
+    if args.batch == 512:   # HBM bytes per launch from the committed PMC passes (same kernels, same shapes)
+        for o, key in zip(others, ("mlp_fwd_kernel", "mlp_bwd_kernel", "wgrad_group_kernel")):
+            pm = committed_pmc(key)
+            o["traffic"] = pm["hbm_bytes_per_launch"] if pm else None
     if rank == 0:
         flops = ATTN_FWD_FLOP_PER_IMG_LAYER * args.batch
         achieved = flops / (fwd_ms * 1e-3) / 1e12
@@ -186,6 +242,8 @@ def main():
                          "bwd_launch_ms": round(bwd_ms, 5),
                          "bwd_achieved_tflops": round(2 * flops / (bwd_ms * 1e-3) / 1e12, 2)},
         }
+        if others:
+            line["other_kernels"] = others
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.pos_encoding)
         print(json.dumps(line), flush=True)

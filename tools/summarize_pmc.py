@@ -10,8 +10,13 @@ def load(d):
     return agg
 F, W, S = load("pmcA_fetch"), load("pmcA_write"), load("pmcA_sq")
 res = {}
-for kind in ("attn_fwd_kernel", "attn_bwd_kernel"):
-    kf = [k for k in F if kind in k][0]
+KINDS = {"attn_fwd_kernel": "attn_fwd_kernel", "attn_bwd_kernel": "attn_bwd_kernel", "mlp_fwd_kernel": "mlp_fwd_kernelIDF16bLi0E",
+         "mlp_bwd_kernel": "vitpe::mlp_fwd_kernel<", "wgrad_group_kernel": "wgrad_group_kernel"}
+for kind, pat in KINDS.items():
+    hits = [k for k in F if pat in k]
+    if not hits:
+        continue
+    kf = hits[0]
     fetch_kb = st.median(F[kf]["FETCH_SIZE"]); write_kb = st.median(W[kf]["WRITE_SIZE"])
     sq = S[kf]
     res[kind] = {
