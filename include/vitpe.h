@@ -190,6 +190,13 @@ int vitpe_reduce_partials(const float* partial, int nparts, int len0, int len1, 
 /* img [B,C,S,S] fp32 -> patches [B*P, C*p*p] T, column = c*p*p + ky*p + kx                    */
 int vitpe_unfold(int dtype, const float* img, void* patches, int B, int C, int S, int p,
                  vitpe_stream_t stream);
+/* The same from a uint8 dataset resident in HBM -- replaces the DataLoader gather + ToTensor + Normalize
+ * of train.py:69-92 in front of the patch embed: record index[b] (NULL: record b) of data [Ndata,C,S,S]
+ * uint8 is turned into ((x/255) - mean[c]) / std[c] (fp32, the reference's operation order) and written as
+ * the patch matrix; img_out (nullable) receives the normalised fp32 image [B,C,S,S].                   */
+int vitpe_unfold_u8(int dtype, const unsigned char* data, const long long* index, const float* mean,
+                    const float* stdv, void* patches, float* img_out, int B, int C, int S, int p,
+                    vitpe_stream_t stream);
 /* dcls[d] += sum_b dtok[b,0,d]; dape[p,d] += sum_b dtok[b,1+p,d] (NULL to skip);
  * dpatch [B*P,D] T = patch rows of dtok (input of the patch-embed weight gradient)            */
 int vitpe_embed_bwd(int dtype, const void* dtok, float* dcls, float* dape, void* dpatch, int B,

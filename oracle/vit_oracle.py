@@ -261,6 +261,23 @@ def mlp(x, w1, b1, w2, b2):
     return F.linear(F.gelu(F.linear(x, w1, b1)), w2, b2)
 
 
+DATASET_STATS = {   # reference train.py:72,81 (transforms.Normalize arguments)
+    "mnist": ((0.1307,), (0.3081,)),
+    "cifar10": ((0.4914, 0.4822, 0.4465), (0.2023, 0.1994, 0.2010)),
+}
+
+
+def normalize_u8(images_u8: torch.Tensor, mean, std) -> torch.Tensor:
+    """uint8 [B,C,S,S] -> fp32: transforms.ToTensor (x / 255) then transforms.Normalize ((x - mean) / std), the
+    input transform of reference train.py:69-82 (Resize is the identity at img_size 32 for CIFAR-10).
+    torchvision is absent from the build image: this restates its published ToTensor / Normalize arithmetic
+    (fp32 division by 255, then sub_, div_) -- "parity unpinned" against torchvision itself."""
+    x = images_u8.to(torch.float32) / 255.0
+    m = torch.tensor(mean, dtype=torch.float32).view(1, -1, 1, 1)
+    sd = torch.tensor(std, dtype=torch.float32).view(1, -1, 1, 1)
+    return (x - m) / sd
+
+
 def patch_embed(cfg: VitConfig, params, images):
     """Conv2d(k=s=p) == unfold + GEMM; flatten/transpose; prepend cls; APE.
 

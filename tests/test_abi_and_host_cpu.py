@@ -119,3 +119,75 @@ def test_cpu_tensors_are_refused_not_computed():
     m = VisionTransformer(embed_dim=96, depth=1, num_heads=3, pos_encoding="none")
     with pytest.raises(VitpeError, match="no CPU fallback"):
         m(torch.zeros(2, 3, 32, 32))
+
+
+# ---- resident input pipeline: file readers, sharding, the oracle's transform ----------------
+def _write_cifar_bin(path, n, seed):
+    rng = np.random.default_rng(seed)
+    rec = np.zeros((n, 3073), dtype=np.uint8)
+    rec[:, 0] = rng.integers(0, 10, n)
+    rec[:, 1:] = rng.integers(0, 256, (n, 3072))
+    rec.tofile(path)
+    return rec
+
+
+def test_cifar10_binary_reader_and_mnist_idx_reader(tmp_path):
+    import struct
+    from vitpe import data as D
+    from vitpe._lib import VitpeError
+    recs = [_write_cifar_bin(tmp_path / f"data_batch_{i}.bin", 7, i) for i in range(1, 6)]
+    test = _write_cifar_bin(tmp_path / "test_batch.bin", 5, 9)
+    x, y = D.read_cifar10_bin(str(tmp_path), True)
+    assert x.shape == (35, 3, 32, 32) and x.dtype == np.uint8 and y.dtype == np.int64
+    allrec = np.concatenate(recs)
+    assert np.array_equal(y, allrec[:, 0]) and np.array_equal(x.reshape(35, -1), allrec[:, 1:])   # channel-planar records
+    xt, yt = D.read_cifar10_bin(str(tmp_path), False)
+    assert np.array_equal(xt.reshape(5, -1), test[:, 1:]) and np.array_equal(yt, test[:, 0])
+    (tmp_path / "data_batch_3.bin").write_bytes(b"\x00" * 100)
+    with pytest.raises(VitpeError):
+        D.read_cifar10_bin(str(tmp_path), True)
+    # MNIST idx
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (4, 28, 28), dtype=np.uint8)
+    lab = rng.integers(0, 10, 4).astype(np.uint8)
+    (tmp_path / "t10k-images-idx3-ubyte").write_bytes(struct.pack(">IIII", 0x803, 4, 28, 28) + img.tobytes())
+    (tmp_path / "t10k-labels-idx1-ubyte").write_bytes(struct.pack(">II", 0x801, 4) + lab.tobytes())
+    xm, ym = D.read_mnist_idx(str(tmp_path), False, 32)
+    assert xm.shape == (4, 1, 32, 32) and xm.dtype == np.uint8 and np.array_equal(ym, lab)
+    x28, _ = D.read_mnist_idx(str(tmp_path), False, 28)
+    assert np.array_equal(x28[:, 0], img)
+    with pytest.raises(VitpeError):
+        D.read_mnist_idx(str(tmp_path), True)   # train files absent / wrong magic is an error, never a download
+
+
+def test_epoch_batches_shard_and_reshuffle():
+    from vitpe import data as D
+    n, batch, world = 103, 8, 3
+    per_epoch = []
+    for epoch in range(2):
+        seen = []
+        for rank in range(world):
+            bs = list(D.epoch_batches(n, batch, epoch, seed=5, shuffle=True, rank=rank, world=world, device="cpu"))
+            assert all(b.shape == (batch,) and b.dtype == torch.int64 for b in bs) and len(bs) == (n // world) // batch
+            seen += [int(i) for b in bs for i in b]
+        assert len(seen) == len(set(seen)) and max(seen) < n      # disjoint shards of one permutation
+        per_epoch.append(seen)
+    assert per_epoch[0] != per_epoch[1]                            # reshuffled every epoch
+    again = [int(i) for b in D.epoch_batches(n, batch, 0, seed=5, rank=0, world=world, device="cpu") for i in b]
+    assert again == per_epoch[0][:len(again)]                      # deterministic given (seed, epoch)
+    order = [int(i) for b in D.epoch_batches(20, 5, 0, shuffle=False, device="cpu") for i in b]
+    assert order == list(range(20))
+    assert D.shard_slice(103, 2, 3) == (68, 102)
+
+
+def test_oracle_input_transform_matches_its_definition():
+    from oracle import vit_oracle as O
+    x = torch.arange(0, 256, dtype=torch.uint8).repeat(3 * 4)[: 3 * 16 * 16].reshape(1, 3, 16, 16)
+    mean, std = O.DATASET_STATS["cifar10"]
+    y = O.normalize_u8(x, mean, std)
+    assert y.dtype == torch.float32 and y.shape == x.shape
+    for c in range(3):
+        v = x[0, c].float() / 255.0
+        assert torch.equal(y[0, c], (v - mean[c]) / std[c])
+    from vitpe import data as D
+    assert D.DATASET_STATS == O.DATASET_STATS                     # train.py:72,81 constants on both sides

@@ -634,3 +634,28 @@ def test_embed_bwd(K):
     assert rel_err(dcls.cpu(), dtok[:, 0].sum(0)) < 1e-5
     assert rel_err(dape.cpu(), dtok[:, 1:].sum(0)) < 1e-5
     assert torch.equal(dpatch.cpu(), dtok[:, 1:].reshape(-1, D))
+
+
+# ---- resident uint8 input ---------------------------------------------------------------
+@pytest.mark.parametrize("C,S,p,name", [(3, 32, 4, "cifar10"), (1, 32, 4, "mnist"), (3, 224, 16, "cifar10")])
+def test_unfold_u8_gather_normalise_unfold(K, C, S, p, name):
+    """vitpe_unfold_u8 == DataLoader gather + ToTensor + Normalize (oracle restatement of train.py:69-82)
+    + the fp32 unfold; fp32 output bit-exact (same operations in the same order), bf16 = its rounding."""
+    g = torch.Generator().manual_seed(S + C)
+    data = torch.randint(0, 256, (37, C, S, S), generator=g, dtype=torch.uint8)
+    idx = torch.randperm(37, generator=g)[:9]
+    mean, std = O.DATASET_STATS[name]
+    ref_img = O.normalize_u8(data[idx], mean, std)
+    ref_patches = K.unfold(ref_img.cuda(), p, torch.float32).cpu()
+    md, sd = torch.tensor(mean).cuda(), torch.tensor(std).cuda()
+    img_out = torch.empty(9, C, S, S, device="cuda")
+    got = K.unfold_u8(data.cuda(), idx.cuda(), md, sd, p, torch.float32, img_out=img_out)
+    assert torch.equal(img_out.cpu(), ref_img)
+    assert torch.equal(got.cpu(), ref_patches)
+    got16 = K.unfold_u8(data.cuda(), idx.cuda(), md, sd, p, torch.bfloat16)
+    assert torch.equal(got16.cpu(), ref_patches.to(torch.bfloat16))
+    first = K.unfold_u8(data.cuda(), None, md, sd, p, torch.float32)        # NULL index: records in order
+    assert torch.equal(first.cpu(), K.unfold(O.normalize_u8(data, mean, std).cuda(), p, torch.float32).cpu())
+    from vitpe._lib import VitpeError
+    with pytest.raises(VitpeError):
+        K.unfold_u8(data.float().cuda(), idx.cuda(), md, sd, p, torch.float32)

@@ -285,3 +285,84 @@ def test_ragged_batch_through_dropin_module():
             ref = O.forward(cfg, params, images)
             out = model(images.cuda())
         assert out.shape == (B, 10) and rel_err(out.cpu(), ref) < 1e-4
+
+
+def test_engine_on_resident_uint8_dataset_equals_engine_on_normalised_images():
+    """attach_dataset + step_indexed (pixels gathered / normalised inside the unfold kernel, graph replay) gives the
+    same parameters as feeding the same samples as pre-normalised fp32 images (oracle transform), fp32 mode."""
+    from vitpe.data import ResidentDataset
+    from vitpe.engine import TrainEngine
+    B = 6
+    g = torch.Generator().manual_seed(3)
+    data = torch.randint(0, 256, (40, 3, 32, 32), generator=g, dtype=torch.uint8)
+    labels = torch.randint(0, 10, (40,), generator=g)
+    mean, std = O.DATASET_STATS["cifar10"]
+    ds = ResidentDataset(data, labels, mean, std, "cuda")
+    engines = []
+    for resident in (True, False):
+        cfg, model = build("rope-axial", {}, SMALL)
+        eng = TrainEngine(model, B, compute_dtype=torch.float32, use_graph=True)
+        if resident:
+            eng.attach_dataset(ds)
+        engines.append(eng)
+    # one forward+backward: identical inputs -> identical logits; gradients differ only by the atomics' order
+    idx = torch.randperm(40, generator=g)[:B]
+    engines[0]._load_indices(idx.cuda())
+    engines[1].images.copy_(O.normalize_u8(data[idx], mean, std))
+    engines[1].labels.copy_(labels[idx])
+    for e in engines:
+        e.forward_backward()
+    assert torch.equal(engines[0].patches.cpu(), engines[1].patches.cpu())
+    assert torch.equal(engines[0].logits.cpu(), engines[1].logits.cpu())
+    assert rel_err(engines[0].flat_g.cpu(), engines[1].flat_g.cpu()) < 1e-5
+    for e in engines:
+        e.flat_g.zero_()
+    # a few graph-replayed steps (Adam amplifies the summation-order noise: loose comparison of the losses)
+    for step in range(3):
+        idx = torch.randperm(40, generator=g)[:B]
+        engines[0].step_indexed(idx.cuda())
+        engines[1].step(O.normalize_u8(data[idx], mean, std).cuda(), labels[idx].cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(engines[0].labels.cpu(), engines[1].labels.cpu())
+    l0, l1 = engines[0].read_metrics()[0], engines[1].read_metrics()[0]
+    assert abs(l0 - l1) < 1e-3 * max(1.0, abs(l1))
+    # evaluation on another dataset leaves the captured training graph alone
+    test_ds = ResidentDataset(data[:12], labels[:12], mean, std, "cuda")
+    logits = engines[0].forward_indexed(torch.arange(B).cuda(), test_ds)
+    logits = logits.clone()
+    engines[0].flat_p.copy_(engines[1].flat_p); engines[0].refresh_shadows()
+    logits = engines[0].forward_indexed(torch.arange(B).cuda(), test_ds).clone()
+    ref = engines[1].forward_only(O.normalize_u8(data[:B], mean, std).cuda())
+    assert torch.equal(logits.cpu(), ref.cpu())
+    from vitpe._lib import VitpeError
+    with pytest.raises(VitpeError):
+        engines[1].step_indexed(torch.arange(B).cuda())          # no dataset attached
+    with pytest.raises(VitpeError):
+        engines[0].step_indexed(torch.arange(B + 1).cuda())      # wrong batch
+
+
+def test_train_py_runs_on_a_dataset_in_binary_format(tmp_path):
+    """train.py end to end on CIFAR-10-format files (synthetic content): resident pipeline, 2 epochs, checkpoint
+    with the reference's file name, CSV log with the reference's header."""
+    import numpy as np
+    import train as T
+    rng = np.random.default_rng(0)
+    root = tmp_path / "data" / "cifar-10-batches-bin"
+    root.mkdir(parents=True)
+    for name, n in [(f"data_batch_{i}.bin", 40) for i in range(1, 6)] + [("test_batch.bin", 64)]:
+        rec = np.zeros((n, 3073), dtype=np.uint8)
+        rec[:, 0] = rng.integers(0, 10, n)
+        rec[:, 1:] = rng.integers(0, 256, (n, 3072))
+        rec.tofile(root / name)
+    T.main(["--dataset", "cifar10", "--pos_encoding", "rope-mixed", "--batch_size", "32", "--epochs", "2",
+            "--embed_dim", "96", "--depth", "2", "--num_heads", "3", "--data_dir", str(tmp_path / "data"),
+            "--log_dir", str(tmp_path / "logs"), "--ckpt_dir", str(tmp_path / "ckpt")])
+    ck = tmp_path / "ckpt" / "cifar10_rope-mixed_best.pth"
+    assert ck.exists()
+    sd = torch.load(ck, weights_only=True)
+    assert "blocks.0.attn.pos_encoding.freqs" in sd and "pos_embed.freqs" in sd
+    logs = list((tmp_path / "logs").glob("cifar10_rope-mixed_*.csv"))
+    rows = logs[0].read_text().strip().splitlines()
+    assert rows[0] == "epoch,train_loss,train_acc,test_loss,test_acc,best_acc" and len(rows) == 3
+    with pytest.raises(SystemExit):
+        T.main(["--dataset", "mnist", "--data_dir", str(tmp_path / "nothing_here"), "--epochs", "1"])

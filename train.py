@@ -52,6 +52,10 @@ def get_args(argv=None):
     parser.add_argument('--synthetic', action='store_true', help='dataset-shaped random batches generated on the device')
     parser.add_argument('--steps_per_epoch', type=int, default=0, help='0 = dataset size // batch_size')
     parser.add_argument('--fp32', action='store_true', help='exact-fp32 MFMA instead of bf16')
+    parser.add_argument('--data_dir', type=str, default='./data',
+                        help='directory holding the dataset in its binary format (CIFAR-10 binary batches / MNIST idx '
+                             'files); it is loaded once into HBM as uint8 (no download: there is no network here)')
+    parser.add_argument('--seed', type=int, default=0, help='seed of the per-epoch shuffle')
     return parser.parse_args(argv)
 
 
@@ -78,13 +82,40 @@ class SyntheticBatches:
             yield self.images[i % len(self.images)], self.labels[i % len(self.labels)]
 
 
-def get_dataset(args, info, per_rank_batch, device, rank):
+class ResidentBatches:
+    """One epoch's index batches over a `vitpe.data.ResidentDataset` (reference DataLoader(shuffle=...),
+    train.py:89-90): the loop hands the engine sample indices, the pixels never leave HBM."""
+
+    def __init__(self, dataset, batch, shuffle, seed, rank, world):
+        self.ds, self.batch, self.shuffle, self.seed, self.rank, self.world = dataset, batch, shuffle, seed, rank, world
+        self.epoch = 0
+
+    def __len__(self):
+        return (len(self.ds) // self.world) // self.batch
+
+    def __iter__(self):
+        from vitpe.data import epoch_batches
+        it = epoch_batches(len(self.ds), self.batch, self.epoch, self.seed, self.shuffle, self.rank, self.world,
+                           self.ds.device)
+        self.epoch += 1
+        for idx in it:
+            yield idx, None
+
+
+def get_dataset(args, info, per_rank_batch, device, rank, world=1):
     if not args.synthetic:
+        from vitpe._lib import VitpeError
+        from vitpe.data import ResidentDataset
+        root = os.path.join(args.data_dir, {'cifar10': 'cifar-10-batches-bin', 'mnist': 'MNIST/raw'}[args.dataset])
+        root = root if os.path.isdir(root) else args.data_dir
         try:
-            import torchvision  # noqa: F401
-        except ImportError:
-            raise SystemExit("torchvision / dataset download unavailable here: re-run with --synthetic")
-        raise SystemExit("real-data input pipeline is not part of this round (SURVEY 8f-3): use --synthetic")
+            tr = ResidentDataset.from_files(args.dataset, root, True, device, args.img_size)
+            te = ResidentDataset.from_files(args.dataset, root, False, device, args.img_size)
+        except VitpeError as e:
+            raise SystemExit(f"{e}\nno dataset under {args.data_dir} (nothing is downloaded here): "
+                             f"place the binary files there or re-run with --synthetic")
+        return (ResidentBatches(tr, per_rank_batch, True, args.seed, rank, world),
+                ResidentBatches(te, per_rank_batch, False, args.seed, rank, world))
     n_train = args.steps_per_epoch or info['train'] // args.batch_size
     n_test = max(1, min(n_train // 5, info['test'] // args.batch_size))
     mk = lambda n, seed: SyntheticBatches(n, per_rank_batch, info['in_chans'], args.img_size,  # noqa: E731
@@ -95,8 +126,14 @@ def get_dataset(args, info, per_rank_batch, device, rank):
 def train(engine, loader):
     """One epoch (reference train.py:94-125) -> (avg_loss, acc%). No per-step host sync."""
     seen = 0
+    resident = isinstance(loader, ResidentBatches)
+    if resident:
+        engine.attach_dataset(loader.ds)
     for images, labels in loader:
-        engine.step(images, labels)
+        if resident:
+            engine.step_indexed(images)
+        else:
+            engine.step(images, labels)
         seen += images.shape[0]
     loss_sum, correct = engine.read_metrics()
     return loss_sum / max(len(loader), 1), 100. * correct / max(seen, 1)
@@ -107,8 +144,12 @@ def test(engine, loader):
     from vitpe import kernels as K
     loss_sum, correct, seen = 0.0, 0.0, 0
     acc = torch.zeros(2, device=engine.dev)
+    resident = isinstance(loader, ResidentBatches)
     for images, labels in loader:
-        logits = engine.forward_only(images)
+        if resident:
+            logits, labels = engine.forward_indexed(images, loader.ds), engine.labels
+        else:
+            logits = engine.forward_only(images)
         out2, _ = K.cross_entropy(logits, labels, want_grad=False)
         acc += out2
         seen += images.shape[0]
@@ -141,7 +182,7 @@ def main(argv=None):
         with open(log_file, 'w', newline='') as f:
             csv.writer(f).writerow(['epoch', 'train_loss', 'train_acc', 'test_loss', 'test_acc', 'best_acc'])
 
-    train_loader, test_loader = get_dataset(args, info, per_rank, device, rank)
+    train_loader, test_loader = get_dataset(args, info, per_rank, device, rank, world)
     torch.manual_seed(0)
     model = VisionTransformer(img_size=args.img_size, patch_size=args.patch_size, in_chans=info['in_chans'],
                               num_classes=info['num_classes'], embed_dim=args.embed_dim, depth=args.depth,

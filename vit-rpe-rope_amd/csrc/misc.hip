@@ -26,6 +26,37 @@ __global__ void unfold_kernel(const float* __restrict__ img, T* __restrict__ pat
   }
 }
 
+// Same from a uint8 dataset resident in HBM (reference train.py:69-92: DataLoader gather ->
+// ToTensor (x/255) -> Normalize((x-mean)/std) -> model): record index[b] of data [Ndata,C,S,S] (the
+// CIFAR-10 binary / MNIST idx pixel order) is normalised in fp32 with the reference's operation
+// order and written straight as the patch matrix; img_out (nullable) receives the fp32 image.
+template <typename T>
+__global__ void unfold_u8_kernel(const unsigned char* __restrict__ data, const long long* __restrict__ index,
+                                 const float* __restrict__ mean, const float* __restrict__ stdv, T* __restrict__ patches,
+                                 float* __restrict__ img_out, int B, int Cc, int S, int p) {
+  const int g = S / p, P = g * g, Kp = Cc * p * p;
+  const long long total = (long long)B * P * Cc * p;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int ky = (int)(idx % p);
+    long long t = idx / p;
+    const int ch = (int)(t % Cc); t /= Cc;
+    const int n = (int)(t % P);
+    const int b = (int)(t / P);
+    const int gy = n / g, gx = n % g;
+    const long long rec = index != nullptr ? index[b] : (long long)b;
+    const size_t pix = ((size_t)ch * S + gy * p + ky) * S + gx * p;
+    const unsigned char* src = data + (size_t)rec * Cc * S * S + pix;
+    T* dst = patches + ((size_t)b * P + n) * Kp + ch * p * p + ky * p;
+    const float m = mean[ch], sd = stdv[ch];
+    for (int kx = 0; kx < p; ++kx) {
+      const float v = ((float)src[kx] / 255.0f - m) / sd;   // ToTensor then Normalize, IEEE division
+      dst[kx] = from_f32<T>(v);
+      if (img_out != nullptr) img_out[(size_t)b * Cc * S * S + pix + kx] = v;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Integer tables (bit-exact contract)
 __global__ void rel_index_kernel(long long* out, int L) {  // positional_encoding.py:67-75
@@ -388,6 +419,20 @@ extern "C" int vitpe_unfold(int dtype, const float* img, void* patches, int B, i
   const unsigned blocks = (unsigned)min((total + 255) / 256, (long long)8192);
   if (dtype == 1) hipLaunchKernelGGL(unfold_kernel<bf16>, dim3(blocks), dim3(256), 0, st, img, (bf16*)patches, B, C, S, p);
   else hipLaunchKernelGGL(unfold_kernel<float>, dim3(blocks), dim3(256), 0, st, img, (float*)patches, B, C, S, p);
+  VITPE_CHECK_LAUNCH();
+}
+
+extern "C" int vitpe_unfold_u8(int dtype, const unsigned char* data, const long long* index, const float* mean,
+                               const float* stdv, void* patches, float* img_out, int B, int C, int S, int p,
+                               hipStream_t st) {
+  VITPE_REQUIRE(data && mean && stdv && patches && B >= 0 && C > 0 && p > 0 && S % p == 0 && (dtype == 0 || dtype == 1));
+  const long long total = (long long)B * (S / p) * (S / p) * C * p;
+  if (total == 0) return 0;
+  const unsigned blocks = (unsigned)min((total + 255) / 256, (long long)8192);
+  if (dtype == 1)
+    hipLaunchKernelGGL(unfold_u8_kernel<bf16>, dim3(blocks), dim3(256), 0, st, data, index, mean, stdv, (bf16*)patches, img_out, B, C, S, p);
+  else
+    hipLaunchKernelGGL(unfold_u8_kernel<float>, dim3(blocks), dim3(256), 0, st, data, index, mean, stdv, (float*)patches, img_out, B, C, S, p);
   VITPE_CHECK_LAUNCH();
 }
 

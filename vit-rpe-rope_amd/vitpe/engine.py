@@ -189,6 +189,7 @@ class TrainEngine:
         self.dqkv_l = [e(B, N, 3 * D) for _ in range(self.Lyr)]
         self.dqkv, self.du = self.dqkv_l[0], self.du_l[0]          # (bench.py times the kernels on these)
         self.side = torch.cuda.Stream(device=dev)
+        self.dataset, self.batch_idx = None, None
         self.overlap_wgrad = __import__("os").environ.get("VITPE_OVERLAP_WGRAD", "0") == "1"
         # weight gradients: one grouped launch per backward part (default) or one GEMM per nn.Linear
         self.group_wgrad = __import__("os").environ.get("VITPE_GROUP_WGRAD", "1") == "1" and not self.overlap_wgrad
@@ -216,7 +217,11 @@ class TrainEngine:
     # ---------------------------------------------------------------- forward / backward
     def _forward(self):
         mdl, B, N, D, M = self.model, self.B, self.N, self.D, self.M
-        K.unfold(self.images, self.p, self.T, out=self.patches)
+        if self.dataset is not None:   # resident uint8 dataset: gather + ToTensor + Normalize inside the unfold
+            K.unfold_u8(self.dataset.images, self.batch_idx, self.dataset.mean, self.dataset.std, self.p, self.T,
+                        out=self.patches)
+        else:
+            K.unfold(self.images, self.p, self.T, out=self.patches)
         ape = mdl.pos_embed.pos_embed.data[0, :self.P] if isinstance(mdl.pos_embed, AbsolutePositionalEncoding) else None
         K.patch_embed_gemm(self.patches, self.Sh(mdl.patch_embed.weight).view(D, -1), mdl.patch_embed.bias.data,
                            mdl.cls_token.data.view(-1), ape, B, self.P, out=self.x[0])
@@ -428,6 +433,50 @@ class TrainEngine:
             with torch.cuda.graph(self.graph_opt, capture_error_mode="thread_local"):
                 self._optimizer()
         torch.cuda.synchronize()
+
+    def attach_dataset(self, dataset):
+        """Feed the engine from a `vitpe.data.ResidentDataset` (uint8 images in HBM): steps then take sample
+        indices (`step_indexed`) instead of image tensors.  `None` detaches.  Captured graphs are dropped."""
+        if dataset is self.dataset:
+            return
+        if dataset is not None:
+            C, S = dataset.images.shape[1], dataset.images.shape[2]
+            if (C, S) != (self.C, self.S) or dataset.images.device != self.dev:
+                raise L.VitpeError(f"dataset is {C}x{S}x{S} on {dataset.images.device}, engine expects "
+                                   f"{self.C}x{self.S}x{self.S} on {self.dev}")
+            if self.batch_idx is None:
+                self.batch_idx = torch.zeros(self.B, dtype=torch.int64, device=self.dev)
+        self.dataset = dataset
+        self.graph_fb = self.graph_fb2 = self.graph_opt = None
+
+    def _load_indices(self, idx: torch.Tensor, dataset=None):
+        dataset = dataset if dataset is not None else self.dataset
+        if dataset is None:
+            raise L.VitpeError("no dataset attached (TrainEngine.attach_dataset)")
+        if idx.shape != (self.B,) or idx.dtype != torch.int64:
+            raise L.VitpeError(f"expected {self.B} int64 sample indices, got {tuple(idx.shape)} {idx.dtype}")
+        self.batch_idx.copy_(idx, non_blocking=True)
+        torch.index_select(dataset.labels, 0, self.batch_idx, out=self.labels)
+
+    def step_indexed(self, idx: torch.Tensor):
+        """One training step on samples `idx` [B] (int64, device) of the attached resident dataset."""
+        self._load_indices(idx)
+        self.step()
+
+    def forward_indexed(self, idx: torch.Tensor, dataset=None) -> torch.Tensor:
+        """Logits for samples `idx` of `dataset` (default: the attached one), eager forward (evaluation); the
+        labels land in `self.labels`.  Another dataset does not disturb the captured training graphs."""
+        keep = self.dataset
+        if dataset is not None:
+            if self.batch_idx is None:
+                self.batch_idx = torch.zeros(self.B, dtype=torch.int64, device=self.dev)
+            self.dataset = dataset
+        try:
+            self._load_indices(idx)
+            self._forward()
+        finally:
+            self.dataset = keep
+        return self.logits
 
     def step(self, images: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None):
         """One training step (train.py:109-116).  `images` [B,C,S,S] fp32 / `labels` [B] int64 on the

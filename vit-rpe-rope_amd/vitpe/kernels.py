@@ -326,6 +326,22 @@ def unfold(images, patch, dtype, out=None):
     return o
 
 
+def unfold_u8(data, index, mean, std, patch, dtype, out=None, img_out=None):
+    """Resident uint8 dataset [Ndata,C,S,S] + sample indices [B] int64 (None: the first rows) -> normalised
+    patch matrix [B*P, C*p*p] (ToTensor + Normalize + unfold in one pass); img_out optionally gets the fp32 images."""
+    require_device(data, index, mean, std, out, img_out)
+    if data.dtype != torch.uint8 or (index is not None and index.dtype != torch.int64):
+        raise L.VitpeError("unfold_u8: data must be uint8 and index int64")
+    _f32(mean, "mean"), _f32(std, "std"), _f32(img_out, "img_out")
+    _, C, S, _ = data.shape
+    B = index.shape[0] if index is not None else data.shape[0]
+    g = S // patch
+    o = out if out is not None else torch.empty((B * g * g, C * patch * patch), dtype=dtype, device=data.device)
+    check(lib().vitpe_unfold_u8(dtype_code(dtype), ptr(data), ptr(index), ptr(mean), ptr(std), ptr(o), ptr(img_out), B, C, S,
+                                patch, stream_ptr()), "vitpe_unfold_u8")
+    return o
+
+
 def embed_bwd(dtok, dcls, dape, out=None):
     require_device(dtok, dcls, dape, out)
     B, Ntok, D = dtok.shape
