@@ -851,11 +851,8 @@ static int launch_gemm_tn(GemmTNArgs a, int splits, hipStream_t s) {
   a.rows_per_split = rps;
   const int nz = (a.M + rps - 1) / rps;
   dim3 block(256);
-  if (false && a.K % 192 == 0) {  // 128x192 tiles: fewer panel re-reads but LDS-read bound on the transposed
-                                   // fragment reads (measured 15 % slower than 128x64) -- kept for the redesign
-    dim3 grid(((a.N + 127) / 128) * (a.K / 192) * nz);
-    hipLaunchKernelGGL((gemm_tn_kernel<T, 192>), grid, block, 0, s, a);
-  } else if (a.K % 128 == 0 || a.K > 192) {
+  // (128 x 192 tiles were measured 15 % slower: LDS-read bound on the transposed fragment reads)
+  if (a.K % 128 == 0 || a.K > 192) {
     dim3 grid(((a.N + 127) / 128) * ((a.K + 127) / 128) * nz);
     hipLaunchKernelGGL((gemm_tn_kernel<T, 128>), grid, block, 0, s, a);
   } else {
@@ -872,9 +869,5 @@ extern "C" int vitpe_gemm_tn(int dtype, const void* dY, const void* X, float* dW
   VITPE_REQUIRE(N % (dtype == 1 ? 8 : 4) == 0 && K % (dtype == 1 ? 8 : 4) == 0);
   if (M == 0) return 0;
   GemmTNArgs a{dY, X, dW, dbias, M, N, K, 0, (long long)K, 1LL, 0};
-  if (false && K % 192 != 0 && N % 192 == 0) {
-    // swap the roles so the 192-multiple side becomes the full-width side: dW^T = X^T dY
-    a.dY = X; a.X = dY; a.N = K; a.K = N; a.sn = 1; a.sk = K; a.bias_from_x = 1;
-  }
   return dtype == 1 ? launch_gemm_tn<bf16>(a, splits, stream) : launch_gemm_tn<float>(a, splits, stream);
 }

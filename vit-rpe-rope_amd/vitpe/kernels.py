@@ -95,8 +95,8 @@ def patch_embed_gemm(patches, w, bias, cls, ape, B, P, out=None):
 
 
 def wgrad_splits(M, N, K):
-    if True:
-        tiles = ((N + 127) // 128) * ((K + 127) // 128 if (K % 128 == 0 or K > 192) else (K + 63) // 64)
+    """token slices for a single vitpe_gemm_tn launch: enough (n, k) tiles x slices to cover the CUs"""
+    tiles = ((N + 127) // 128) * ((K + 127) // 128 if (K % 128 == 0 or K > 192) else (K + 63) // 64)
     return max(1, min(64, SPLITS_TARGET_WGS // max(tiles, 1), (M + 255) // 256))
 
 
