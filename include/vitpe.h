@@ -145,6 +145,15 @@ int vitpe_mlp_fwd(int dtype, const void* x, const float* gamma, const float* bet
                   const float* rstd, void* xn_out, const void* W1, const float* b1, const void* W2,
                   const float* b2, void* u_out, void* h_out, void* out, float* mean_out, float* rstd_out,
                   float eps, int M, int D, int HID, vitpe_stream_t stream);
+/* vitpe_block_tail_fwd: the attention branch's tail and the MLP branch in one kernel (vit.py:91,122-124):
+ *   x_mid = x_in + attn_out Wp^T + bp ;  out = x_mid + fc2(gelu(fc1(LayerNorm2(x_mid))))
+ * x_mid [M,192] and its LayerNorm statistics mean2 / rstd2 [M] are outputs (backward needs them); everything
+ * else as vitpe_mlp_fwd (eps2: norm2, eps_next: the statistics of `out`).  Same support set.               */
+int vitpe_block_tail_fwd(int dtype, const void* attn_out, const void* x_in, const void* Wp, const float* bp,
+                         const float* gamma, const float* beta, void* x_mid, float* mean2, float* rstd2,
+                         void* xn_out, const void* W1, const float* b1, const void* W2, const float* b2,
+                         void* u_out, void* h_out, void* out, float* mean_out, float* rstd_out, float eps2,
+                         float eps_next, int M, int D, int HID, vitpe_stream_t stream);
 /* vitpe_mlp_bwd: backward of that branch w.r.t. its input, same pipeline on the transposed weight shadows:
  *   du = (dy fc2.weight) * gelu'(u)   [M,HID], stored (the fc1 weight gradient reads it)
  *   dx = dy + LayerNorm'(du fc1.weight) ; dgamma / dbeta accumulated (fp32 atomics)

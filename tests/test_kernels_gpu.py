@@ -257,6 +257,42 @@ def test_fused_mlp_backward(K, M, HID):
     assert rel_err(dgam.cpu(), dg2.cpu()) < 1e-3 and rel_err(dbet.cpu(), db2.cpu()) < 1e-3
 
 
+@pytest.mark.parametrize("M", [650, 130 * 2 + 5])
+def test_block_tail_forward_equals_proj_then_mlp(K, M):
+    """proj + residual + LayerNorm2 statistics + the MLP branch in ONE kernel against the two launches it replaces
+    (vitpe_linear with row statistics, then vitpe_mlp_fwd) and against fp32 math on the rounded operands."""
+    from vitpe import _lib as L
+    D, HID, bf = 192, 768, torch.bfloat16
+    a_, x_in = rnd(M, D, seed=21), rnd(M, D, seed=22)
+    wp, bp = rnd(D, D, seed=23, scale=0.07), 0.1 * rnd(D, seed=24)
+    g, b = 1 + 0.1 * rnd(D, seed=25), 0.1 * rnd(D, seed=26)
+    w1, b1 = rnd(HID, D, seed=27, scale=0.08), 0.1 * rnd(HID, seed=28)
+    w2, b2 = rnd(D, HID, seed=29, scale=0.05), 0.1 * rnd(D, seed=30)
+    mo, ro = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    xn_out = torch.empty(M, D, device="cuda", dtype=bf)
+    out, x_mid, m2, r2, u, h = K.block_tail_fwd(dev(a_, bf), dev(x_in, bf), dev(wp, bf), dev(bp), dev(g), dev(b), dev(w1, bf),
+                                               dev(b1), dev(w2, bf), dev(b2), xn_out=xn_out, stats=(mo, ro))
+    # the launches it replaces
+    m2r, r2r = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    x_mid_r = K.linear(dev(a_, bf), dev(wp, bf), dev(bp), epi=L.EPI_BIAS_RESID, resid=dev(x_in, bf), stats=(m2r, r2r))
+    xn_r = torch.empty_like(xn_out)
+    out_r, u_r, h_r = K.mlp_fwd(x_mid_r, dev(g), dev(b), m2r, r2r, dev(w1, bf), dev(b1), dev(w2, bf), dev(b2), xn_out=xn_r)
+    assert torch.equal(x_mid.cpu(), x_mid_r.cpu())
+    assert rel_err(m2.cpu(), m2r.cpu()) < 1e-6 and rel_err(r2.cpu(), r2r.cpu()) < 1e-6
+    assert rel_err(xn_out.float().cpu(), xn_r.float().cpu()) < 1e-5
+    assert rel_err(u.float().cpu(), u_r.float().cpu()) < 1e-5 and rel_err(h.float().cpu(), h_r.float().cpu()) < 1e-5
+    assert rel_err(out.float().cpu(), out_r.float().cpu()) < 2e-3
+    # fp32 math on the rounded operands
+    xm = q(a_, "bf16") @ q(wp, "bf16").t() + bp + q(x_in, "bf16")
+    assert rel_err(x_mid.float().cpu(), xm) < BF16_TOL
+    xmq = q(xm, "bf16")
+    xn = q(torch.nn.functional.layer_norm(xmq, (D,), g, b), "bf16")
+    ref = xmq + q(torch.nn.functional.gelu(xn @ q(w1, "bf16").t() + b1), "bf16") @ q(w2, "bf16").t() + b2
+    assert rel_err(out.float().cpu(), ref) < BF16_TOL
+    o = out.float().cpu()
+    assert rel_err(mo.cpu(), o.mean(1)) < 1e-4
+
+
 def test_fused_mlp_unsupported_is_an_error(K):
     from vitpe._lib import VitpeError
     z = lambda *s: torch.zeros(*s, device="cuda")  # noqa: E731

@@ -46,6 +46,17 @@ struct MlpFwdArgs {
   float* rstd_out;
   int M, HID, panel_rows;
   float eps;
+  // PRE (forward only): the attention branch's tail runs first in the same workgroup --
+  //   x_mid = pre_r + pre_a Wp^T + pre_b (vit.py:91,122: proj + residual), stored to `xmid_out` together with its
+  //   LayerNorm statistics (mean_w / rstd_w); `x`, `mean`, `rstd` are then not inputs.
+  const void* pre_a;    // [M,192] merged-head attention output
+  const void* pre_w;    // attn.proj.weight [192,192] T
+  const float* pre_b;   // attn.proj.bias [192]
+  const void* pre_r;    // [M,192] block input (residual)
+  void* xmid_out;       // [M,192]
+  float* mean_w;        // [M] statistics of x_mid rows (norm2), written
+  float* rstd_w;
+  float eps_pre;
   const void* u_in;     // MLP_BWD: pre-activation u [M,HID] saved by the forward
   const void* ln_x;     // MLP_BWD: LayerNorm input rows (x_mid) [M,192]
   float* dgamma;        // MLP_BWD: accumulated (fp32 atomics, one per column and workgroup)
@@ -54,8 +65,9 @@ struct MlpFwdArgs {
 
 constexpr int MLP_D = 192, MLP_BM = 144, MLP_ROWB = 128;
 
-template <typename T, int MODE>
+template <typename T, int MODE, bool PRE>
 __global__ __launch_bounds__(768) void mlp_fwd_kernel(MlpFwdArgs a) {
+  static_assert(!(PRE && MODE != MLP_FWD), "the projection prologue exists for the forward kernel only");
   static_assert(sizeof(T) == 2, "bf16 only: the fp32 images would not fit LDS (the engine's fp32 mode runs unfused)");
   constexpr int D = MLP_D, BM = MLP_BM, BN = 192, ROWB = MLP_ROWB, CHN = 8;
   constexpr int SLAB_A = BM * ROWB;           // one K-slab of an A image: [144][64] bf16
@@ -69,21 +81,25 @@ __global__ __launch_bounds__(768) void mlp_fwd_kernel(MlpFwdArgs a) {
   const int wm = wave >> 2, wn = wave & 3;
   const int M = a.M, HID = a.HID;
   const int m0 = blockIdx.x * a.panel_rows, m_end = min(M, m0 + a.panel_rows);
-  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ X = reinterpret_cast<const T*>(PRE ? a.xmid_out : a.x);   // PRE: x_mid is produced here
   const T* __restrict__ W1 = reinterpret_cast<const T*>(a.W1);
   const T* __restrict__ W2 = reinterpret_cast<const T*>(a.W2);
   const Chunk16 zero = {0u, 0u, 0u, 0u};
   const int nchunk = HID / BN;                // hidden chunks
-  const int S = nchunk * 6;                   // weight slabs: per chunk 3 of W1 then 3 of W2
+  constexpr int S0 = PRE ? 3 : 0;             // PRE: three slabs of the projection weight first
+  const int S = S0 + nchunk * 6;              // weight slabs: per chunk 3 of W1 then 3 of W2
 
   // ---- weight slab s -> registers (2 x 16 B per thread) -------------------------------------------
   auto gload = [&](Chunk16* r, int s) {
-    const int j = s / 6, ph = (s % 6) / 3, ks = s % 3;
+    const int sm = s - S0;
+    const int j = sm / 6, ph = (sm % 6) / 3, ks = (sm + 6) % 3;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int q = tid + 768 * i, row = q >> 3, cc = q & 7;
-      const T* src = (ph == 0) ? W1 + (size_t)(j * BN + row) * D + ks * 64 + cc * CHN
-                               : W2 + (size_t)row * HID + j * BN + ks * 64 + cc * CHN;
+      const T* src;
+      if (PRE && s < S0) src = reinterpret_cast<const T*>(a.pre_w) + (size_t)row * D + s * 64 + cc * CHN;
+      else src = (ph == 0) ? W1 + (size_t)(j * BN + row) * D + ks * 64 + cc * CHN
+                           : W2 + (size_t)row * HID + j * BN + ks * 64 + cc * CHN;
       r[i] = *reinterpret_cast<const Chunk16*>(src);
     }
   };
@@ -132,13 +148,14 @@ __global__ __launch_bounds__(768) void mlp_fwd_kernel(MlpFwdArgs a) {
     for (int it = 0; it < ITERS; ++it) {
       const int q = tid + 768 * it, row = q / 24, cc = q % 24;
       v[it] = zero;
-      if (q < TOTAL && m0 + row < m_end) v[it] = *reinterpret_cast<const Chunk16*>(X + (size_t)(m0 + row) * D + cc * CHN);
+      if (q < TOTAL && m0 + row < m_end)
+        v[it] = *reinterpret_cast<const Chunk16*>((PRE ? reinterpret_cast<const T*>(a.pre_a) : X) + (size_t)(m0 + row) * D + cc * CHN);
     }
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int q = tid + 768 * it, row = q / 24, cc = q % 24;
       if (q < TOTAL) {
-        if (MODE == MLP_FWD && m0 + row < m_end) {
+        if (MODE == MLP_FWD && !PRE && m0 + row < m_end) {
           const float mean = a.mean[m0 + row], rstd = a.rstd[m0 + row];
           float f[CHN];
           chunk_to_f32<T>(v[it], f);
@@ -181,10 +198,88 @@ __global__ __launch_bounds__(768) void mlp_fwd_kernel(MlpFwdArgs a) {
     compute(sA, s & 1, acc);
   };
 
+  if (PRE) {
+    // ---- GEMM0: attention branch tail  x_mid = x_in + a Wp^T + bp ; row statistics ; LN2 -> A image of GEMM1 ----
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) step(ks, sXA + ks * SLAB_A, acc1);
+    const float invN0 = 1.0f / (float)BN;
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+      __syncthreads();
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt)
+        *reinterpret_cast<f32x4*>(ep + (16 * wm + c) * EP_LD + wn * 48 + 16 * nt + 4 * g) = acc1[nt][pass];
+      __syncthreads();
+#pragma unroll 1
+      for (int i = 0; i < 2; ++i) {   // 32 lanes per row (24 live)
+        const int row = (tid >> 5) + 24 * i, pc = tid & 31;
+        const bool live = pc < 24;
+        const int lrow = (row >> 4) * 48 + 16 * pass + (row & 15);
+        const int gm = m0 + lrow, gn = pc * 8;
+        const bool ok = live && gm < m_end;
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = 0.f;
+        if (ok) {
+          const f32x4 x0 = *reinterpret_cast<const f32x4*>(ep + row * EP_LD + pc * 8);
+          const f32x4 x1 = *reinterpret_cast<const f32x4*>(ep + row * EP_LD + pc * 8 + 4);
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.pre_b + gn);
+          const f32x4 b1v = *reinterpret_cast<const f32x4*>(a.pre_b + gn + 4);
+          float rv[8];
+          chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(reinterpret_cast<const T*>(a.pre_r) + (size_t)gm * D + gn), rv);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { v[t] = x0[t] + b0[t] + rv[t]; v[4 + t] = x1[t] + b1v[t] + rv[4 + t]; }
+          const Chunk16 xc = f32_to_chunk<T>(v);
+          *reinterpret_cast<Chunk16*>(reinterpret_cast<T*>(a.xmid_out) + (size_t)gm * D + gn) = xc;
+          chunk_to_f32<T>(xc, v);   // statistics and LayerNorm of the values as stored
+        }
+        float sres = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) sres += v[t];
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) sres += __shfl_xor(sres, o, 64);
+        const float mean = sres * invN0;
+        float sq = 0.f;
+        if (ok) {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) { const float d = v[t] - mean; sq += d * d; }
+        }
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        const float rstd = 1.0f / sqrtf(sq * invN0 + a.eps_pre);
+        if (pc == 0 && gm < m_end) { a.mean_w[gm] = mean; a.rstd_w[gm] = rstd; }
+        if (live) {
+          Chunk16 xn = zero;
+          if (ok) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.gamma + gn);
+            const f32x4 g1 = *reinterpret_cast<const f32x4*>(a.gamma + gn + 4);
+            const f32x4 be0 = *reinterpret_cast<const f32x4*>(a.beta + gn);
+            const f32x4 be1 = *reinterpret_cast<const f32x4*>(a.beta + gn + 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              v[t] = (v[t] - mean) * rstd * g0[t] + be0[t];
+              v[4 + t] = (v[4 + t] - mean) * rstd * g1[t] + be1[t];
+            }
+            xn = f32_to_chunk<T>(v);
+            if (a.xn_out != nullptr)
+              __builtin_nontemporal_store(xn, reinterpret_cast<Chunk16*>(reinterpret_cast<T*>(a.xn_out) + (size_t)gm * D + gn));
+          }
+          const int slab = pc >> 3, slot = pc & 7;
+          *reinterpret_cast<Chunk16*>(sXA + slab * SLAB_A + lrow * ROWB + ((slot ^ ((lrow >> 1) & 7)) << 4)) = xn;
+        }
+      }
+    }
+    __syncthreads();   // parked tile consumed, A image of GEMM1 complete
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acc1[i][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
   for (int j = 0; j < nchunk; ++j) {
     // ---- GEMM1: u_j = LN(x) W1[j]^T -------------------------------------------------------------
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks) step(6 * j + ks, sXA + ks * SLAB_A, acc1);
+    for (int ks = 0; ks < 3; ++ks) step(S0 + 6 * j + ks, sXA + ks * SLAB_A, acc1);
     // ---- epilogue 1: + b1, store u, GELU, store h, park h (bf16) as GEMM2's A image ----------------
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass) {
@@ -237,7 +332,7 @@ __global__ __launch_bounds__(768) void mlp_fwd_kernel(MlpFwdArgs a) {
       for (int k = 0; k < 3; ++k) acc1[i][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // ---- GEMM2: out += h_j W2[:, j]^T  (the step's barrier also orders the h image writes) ----------
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks) step(6 * j + 3 + ks, sHB + ks * SLAB_A, acc2);
+    for (int ks = 0; ks < 3; ++ks) step(S0 + 6 * j + 3 + ks, sHB + ks * SLAB_A, acc2);
   }
 
   if (MODE == MLP_BWD) {
@@ -383,15 +478,16 @@ __global__ __launch_bounds__(768) void mlp_fwd_kernel(MlpFwdArgs a) {
 
 using namespace vitpe;
 
-static int mlp_launch(int mode, MlpFwdArgs& a, hipStream_t stream) {
+static int mlp_launch(int mode, MlpFwdArgs& a, hipStream_t stream, bool pre = false) {
   // as many panels as CUs (x waves of them), each <= 144 rows
   const int waves = (a.M + 256 * MLP_BM - 1) / (256 * MLP_BM);
   const int npanels = 256 * waves;
   int rows = (a.M + npanels - 1) / npanels;
   a.panel_rows = rows < 16 ? 16 : rows;
   const int grid = (a.M + a.panel_rows - 1) / a.panel_rows;
-  if (mode == MLP_FWD) hipLaunchKernelGGL((mlp_fwd_kernel<bf16, MLP_FWD>), dim3(grid), dim3(768), 0, stream, a);
-  else hipLaunchKernelGGL((mlp_fwd_kernel<bf16, MLP_BWD>), dim3(grid), dim3(768), 0, stream, a);
+  if (mode == MLP_FWD && pre) hipLaunchKernelGGL((mlp_fwd_kernel<bf16, MLP_FWD, true>), dim3(grid), dim3(768), 0, stream, a);
+  else if (mode == MLP_FWD) hipLaunchKernelGGL((mlp_fwd_kernel<bf16, MLP_FWD, false>), dim3(grid), dim3(768), 0, stream, a);
+  else hipLaunchKernelGGL((mlp_fwd_kernel<bf16, MLP_BWD, false>), dim3(grid), dim3(768), 0, stream, a);
   VITPE_CHECK_LAUNCH();
 }
 
@@ -428,4 +524,25 @@ extern "C" int vitpe_mlp_bwd(int dtype, const void* dy, const void* u, const voi
   a.x = dy; a.gamma = gamma; a.mean = mean; a.rstd = rstd; a.W1 = W2t; a.W2 = W1t; a.u_out = du; a.out = dx;
   a.u_in = u; a.ln_x = x; a.dgamma = dgamma; a.dbeta = dbeta; a.M = M; a.HID = HID;
   return mlp_launch(MLP_BWD, a, stream);
+}
+
+// Attention-branch tail + MLP branch of a block in one kernel (vit.py:91,122-124):
+//   x_mid = x_in + attn_out Wp^T + bp ; out = x_mid + fc2(gelu(fc1(LayerNorm2(x_mid))))
+// x_mid and its LayerNorm statistics (mean2/rstd2) are outputs (the backward pass needs them); the rest as vitpe_mlp_fwd.
+extern "C" int vitpe_block_tail_fwd(int dtype, const void* attn_out, const void* x_in, const void* Wp, const float* bp,
+                                    const float* gamma, const float* beta, void* x_mid, float* mean2, float* rstd2,
+                                    void* xn_out, const void* W1, const float* b1, const void* W2, const float* b2,
+                                    void* u_out, void* h_out, void* out, float* mean_out, float* rstd_out, float eps2,
+                                    float eps_next, int M, int D, int HID, hipStream_t stream) {
+  VITPE_REQUIRE(attn_out && x_in && Wp && bp && gamma && beta && x_mid && mean2 && rstd2 && W1 && b1 && W2 && b2 &&
+                u_out && h_out && out && M >= 0);
+  VITPE_REQUIRE((mean_out == nullptr) == (rstd_out == nullptr));
+  if (!vitpe_mlp_fwd_supported(dtype, D, HID)) return (int)hipErrorNotSupported;
+  if (M == 0) return 0;
+  MlpFwdArgs a{};
+  a.pre_a = attn_out; a.pre_r = x_in; a.pre_w = Wp; a.pre_b = bp; a.xmid_out = x_mid; a.mean_w = mean2; a.rstd_w = rstd2;
+  a.eps_pre = eps2; a.gamma = gamma; a.beta = beta; a.xn_out = xn_out; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2;
+  a.u_out = u_out; a.h_out = h_out; a.out = out; a.mean_out = mean_out; a.rstd_out = rstd_out;
+  a.M = M; a.HID = HID; a.eps = eps_next;
+  return mlp_launch(MLP_FWD, a, stream, true);
 }

@@ -54,6 +54,7 @@ class TrainEngine:
         self.fuse_mlp = (self.fuse_ln and compute_dtype == torch.bfloat16
                          and __import__("os").environ.get("VITPE_FUSE_MLP", "1") == "1"
                          and K.mlp_fwd_supported(compute_dtype, m.embed_dim, m.blocks[0].mlp.fc1.out_features))
+        self.fuse_tail = __import__("os").environ.get("VITPE_FUSE_TAIL", "1") == "1"   # proj folded into the MLP kernel
         self.D, self.H, self.Lyr = m.embed_dim, m.num_heads, len(m.blocks)
         self.p = m.patch_size
         self.C = m.patch_embed.weight.shape[1]
@@ -238,11 +239,19 @@ class TrainEngine:
                 # statistics come out of the producing GEMM's epilogue (proj / previous fc2)
                 K.fused_attention_fwd(xin, self.Pk(blk.attn.qkv.weight), self.H, self.pe, out=a["a"],
                                       ln=(blk.norm1.weight.data, blk.norm1.bias.data, a["m1"], a["r1"]), xn_out=a["xn1"])
+                nxt = (self.act[l + 1]["m1"], self.act[l + 1]["r1"]) if l + 1 < self.Lyr else None
+                eps_next = mdl.blocks[min(l + 1, self.Lyr - 1)].norm1.eps
+                if self.fuse_mlp and self.fuse_tail:   # proj + residual + LN2 + MLP branch: one kernel per block tail
+                    K.block_tail_fwd(a["a"].view(M, D), xin.view(M, D), self.Sh(blk.attn.proj.weight),
+                                     blk.attn.proj.bias.data, blk.norm2.weight.data, blk.norm2.bias.data,
+                                     self.Sh(blk.mlp.fc1.weight), blk.mlp.fc1.bias.data, self.Sh(blk.mlp.fc2.weight),
+                                     blk.mlp.fc2.bias.data, x_mid=a["xmid"].view(M, D), mean2=a["m2"], rstd2=a["r2"],
+                                     xn_out=a["xn2"].view(M, D), u=a["u"], h=a["h"], out=self.x[l + 1].view(M, D),
+                                     stats=nxt, eps2=blk.norm2.eps, eps_next=eps_next)
+                    continue
                 K.linear(a["a"].view(M, D), self.Sh(blk.attn.proj.weight), blk.attn.proj.bias.data,
                          epi=L.EPI_BIAS_RESID, resid=xin.view(M, D), out=a["xmid"].view(M, D), stats=(a["m2"], a["r2"]),
                          eps=blk.norm2.eps)
-                nxt = (self.act[l + 1]["m1"], self.act[l + 1]["r1"]) if l + 1 < self.Lyr else None
-                eps_next = mdl.blocks[min(l + 1, self.Lyr - 1)].norm1.eps
                 if self.fuse_mlp:   # LN2 + fc1 + GELU + fc2 + residual (+ next LN1 statistics) in one kernel
                     K.mlp_fwd(a["xmid"].view(M, D), blk.norm2.weight.data, blk.norm2.bias.data, a["m2"], a["r2"],
                               self.Sh(blk.mlp.fc1.weight), blk.mlp.fc1.bias.data, self.Sh(blk.mlp.fc2.weight),

@@ -136,6 +136,33 @@ def mlp_fwd(x, gamma, beta, mean, rstd, w1, b1, w2, b2, xn_out=None, u=None, h=N
     return out, u, h
 
 
+def block_tail_fwd(attn_out, x_in, wp, bp, gamma, beta, w1, b1, w2, b2, x_mid=None, mean2=None, rstd2=None, xn_out=None,
+                   u=None, h=None, out=None, stats=None, eps2=1e-5, eps_next=1e-5):
+    """x_mid = x_in + proj(attn_out); out = x_mid + mlp(LayerNorm2(x_mid)) in one kernel.
+    Returns (out, x_mid, mean2, rstd2, u, h)."""
+    require_device(attn_out, x_in, wp, bp, gamma, beta, w1, b1, w2, b2, x_mid, mean2, rstd2, xn_out, u, h, out)
+    M, D = attn_out.shape
+    HID = w1.shape[0]
+    assert x_in.shape == (M, D) and wp.shape == (D, D) and w1.shape == (HID, D) and w2.shape == (D, HID)
+    assert attn_out.dtype == x_in.dtype == wp.dtype == w1.dtype == w2.dtype
+    for t_, n_ in ((bp, "bp"), (gamma, "gamma"), (beta, "beta"), (b1, "b1"), (b2, "b2")):
+        _f32(t_, n_)
+    dt, dev = attn_out.dtype, attn_out.device
+    x_mid = x_mid if x_mid is not None else torch.empty((M, D), dtype=dt, device=dev)
+    mean2 = mean2 if mean2 is not None else torch.empty(M, dtype=torch.float32, device=dev)
+    rstd2 = rstd2 if rstd2 is not None else torch.empty(M, dtype=torch.float32, device=dev)
+    u = u if u is not None else torch.empty((M, HID), dtype=dt, device=dev)
+    h = h if h is not None else torch.empty((M, HID), dtype=dt, device=dev)
+    out = out if out is not None else torch.empty((M, D), dtype=dt, device=dev)
+    mo, ro = stats if stats is not None else (None, None)
+    require_device(mo, ro)
+    check(lib().vitpe_block_tail_fwd(dtype_code(dt), ptr(attn_out), ptr(x_in), ptr(wp), ptr(bp), ptr(gamma), ptr(beta),
+                                     ptr(x_mid), ptr(mean2), ptr(rstd2), ptr(xn_out), ptr(w1), ptr(b1), ptr(w2), ptr(b2),
+                                     ptr(u), ptr(h), ptr(out), ptr(mo), ptr(ro), float(eps2), float(eps_next), M, D, HID,
+                                     stream_ptr()), "vitpe_block_tail_fwd")
+    return out, x_mid, mean2, rstd2, u, h
+
+
 def mlp_bwd(dy, u, w2t, w1t, x, mean, rstd, gamma, dgamma, dbeta, du=None, out=None):
     """Backward of mlp_fwd w.r.t. x: -> (dx, du); dgamma/dbeta accumulated.  w2t = fc2.weight^T [HID,192],
     w1t = fc1.weight^T [192,HID]."""
