@@ -162,6 +162,12 @@ int vitpe_block_tail_fwd(int dtype, const void* attn_out, const void* x_in, cons
 int vitpe_mlp_bwd(int dtype, const void* dy, const void* u, const void* W2t, const void* W1t, const void* x,
                   const float* mean, const float* rstd, const float* gamma, void* du, void* dx, float* dgamma,
                   float* dbeta, int M, int D, int HID, vitpe_stream_t stream);
+/* vitpe_block_tail_bwd: vitpe_mlp_bwd plus the data gradient of the attention projection in the same kernel:
+ *   da = dx W_proj  [M,192]  (WpT = attn.proj.weight^T), the input of the attention backward.            */
+int vitpe_block_tail_bwd(int dtype, const void* dy, const void* u, const void* W2t, const void* W1t, const void* x,
+                         const float* mean, const float* rstd, const float* gamma, void* du, void* dx,
+                         float* dgamma, float* dbeta, const void* WpT, void* da, int M, int D, int HID,
+                         vitpe_stream_t stream);
 /* vitpe_gemm_tn: dW[N,K] += dY[M,N]^T X[M,K] ; dbias[N] += colsum(dY) (NULL to skip).  fp32
  * outputs, accumulated with atomics over `splits` token slices.                             */
 int vitpe_gemm_tn(int dtype, const void* dY, const void* X, float* dW, float* dbias, int M, int N,

@@ -293,6 +293,26 @@ def test_block_tail_forward_equals_proj_then_mlp(K, M):
     assert rel_err(mo.cpu(), o.mean(1)) < 1e-4
 
 
+@pytest.mark.parametrize("M", [650, 130 + 77])
+def test_block_tail_backward_equals_mlp_bwd_then_proj_dgrad(K, M):
+    D, HID, bf = 192, 768, torch.bfloat16
+    x, g = rnd(M, D, seed=41), 1 + 0.1 * rnd(D, seed=42)
+    dy, u = rnd(M, D, seed=43), rnd(M, HID, seed=44)
+    w2t, w1t, wpt = rnd(HID, D, seed=45, scale=0.05), rnd(D, HID, seed=46, scale=0.08), rnd(D, D, seed=47, scale=0.07)
+    xd = dev(x, bf)
+    _, mean, rstd = K.layernorm_fwd(xd, dev(g), torch.zeros(D, device="cuda"))
+    args = (dev(dy, bf), dev(u, bf), dev(w2t, bf), dev(w1t, bf), xd, mean, rstd, dev(g))
+    dg1, db1 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    dx, du, da = K.block_tail_bwd(*args, dg1, db1, dev(wpt, bf))
+    dg2, db2 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    dx2, du2 = K.mlp_bwd(*args, dg2, db2)
+    da2 = K.linear(dx2, dev(wpt, bf))
+    assert torch.equal(dx.cpu(), dx2.cpu()) and torch.equal(du.cpu(), du2.cpu())
+    assert rel_err(dg1.cpu(), dg2.cpu()) < 1e-5 and rel_err(db1.cpu(), db2.cpu()) < 1e-5
+    assert rel_err(da.float().cpu(), da2.float().cpu()) < 1e-5
+    assert rel_err(da.float().cpu(), dx.float().cpu() @ q(wpt, "bf16").t()) < BF16_TOL
+
+
 def test_fused_mlp_unsupported_is_an_error(K):
     from vitpe._lib import VitpeError
     z = lambda *s: torch.zeros(*s, device="cuda")  # noqa: E731

@@ -57,6 +57,10 @@ struct MlpFwdArgs {
   float* mean_w;        // [M] statistics of x_mid rows (norm2), written
   float* rstd_w;
   float eps_pre;
+  // POST (backward only): the data gradient of the attention projection runs last in the same workgroup --
+  //   da = dx W_proj  (dx = this kernel's output rows), stored to `post_out` (input of the attention backward)
+  const void* post_w;   // attn.proj.weight^T [192,192] T (transposed shadow)
+  void* post_out;       // [M,192]
   const void* u_in;     // MLP_BWD: pre-activation u [M,HID] saved by the forward
   const void* ln_x;     // MLP_BWD: LayerNorm input rows (x_mid) [M,192]
   float* dgamma;        // MLP_BWD: accumulated (fp32 atomics, one per column and workgroup)
@@ -65,9 +69,10 @@ struct MlpFwdArgs {
 
 constexpr int MLP_D = 192, MLP_BM = 144, MLP_ROWB = 128;
 
-template <typename T, int MODE, bool PRE>
+template <typename T, int MODE, bool PRE>   // PRE: forward = projection prologue, backward = projection-gradient epilogue
 __global__ __launch_bounds__(768) void mlp_fwd_kernel(MlpFwdArgs a) {
-  static_assert(!(PRE && MODE != MLP_FWD), "the projection prologue exists for the forward kernel only");
+  constexpr bool POST = PRE && MODE == MLP_BWD;
+  constexpr bool FPRE = PRE && MODE == MLP_FWD;
   static_assert(sizeof(T) == 2, "bf16 only: the fp32 images would not fit LDS (the engine's fp32 mode runs unfused)");
   constexpr int D = MLP_D, BM = MLP_BM, BN = 192, ROWB = MLP_ROWB, CHN = 8;
   constexpr int SLAB_A = BM * ROWB;           // one K-slab of an A image: [144][64] bf16
@@ -81,13 +86,14 @@ __global__ __launch_bounds__(768) void mlp_fwd_kernel(MlpFwdArgs a) {
   const int wm = wave >> 2, wn = wave & 3;
   const int M = a.M, HID = a.HID;
   const int m0 = blockIdx.x * a.panel_rows, m_end = min(M, m0 + a.panel_rows);
-  const T* __restrict__ X = reinterpret_cast<const T*>(PRE ? a.xmid_out : a.x);   // PRE: x_mid is produced here
+  const T* __restrict__ X = reinterpret_cast<const T*>(FPRE ? a.xmid_out : a.x);   // forward PRE: x_mid is produced here
   const T* __restrict__ W1 = reinterpret_cast<const T*>(a.W1);
   const T* __restrict__ W2 = reinterpret_cast<const T*>(a.W2);
   const Chunk16 zero = {0u, 0u, 0u, 0u};
   const int nchunk = HID / BN;                // hidden chunks
-  constexpr int S0 = PRE ? 3 : 0;             // PRE: three slabs of the projection weight first
-  const int S = S0 + nchunk * 6;              // weight slabs: per chunk 3 of W1 then 3 of W2
+  constexpr int S0 = FPRE ? 3 : 0;            // forward PRE: three slabs of the projection weight first
+  const int S1 = S0 + nchunk * 6;             // then per chunk 3 slabs of W1 and 3 of W2
+  const int S = S1 + (POST ? 3 : 0);          // backward POST: three slabs of the transposed projection weight last
 
   // ---- weight slab s -> registers (2 x 16 B per thread) -------------------------------------------
   auto gload = [&](Chunk16* r, int s) {
@@ -97,7 +103,8 @@ __global__ __launch_bounds__(768) void mlp_fwd_kernel(MlpFwdArgs a) {
     for (int i = 0; i < 2; ++i) {
       const int q = tid + 768 * i, row = q >> 3, cc = q & 7;
       const T* src;
-      if (PRE && s < S0) src = reinterpret_cast<const T*>(a.pre_w) + (size_t)row * D + s * 64 + cc * CHN;
+      if (FPRE && s < S0) src = reinterpret_cast<const T*>(a.pre_w) + (size_t)row * D + s * 64 + cc * CHN;
+      else if (POST && s >= S1) src = reinterpret_cast<const T*>(a.post_w) + (size_t)row * D + (s - S1) * 64 + cc * CHN;
       else src = (ph == 0) ? W1 + (size_t)(j * BN + row) * D + ks * 64 + cc * CHN
                            : W2 + (size_t)row * HID + j * BN + ks * 64 + cc * CHN;
       r[i] = *reinterpret_cast<const Chunk16*>(src);
@@ -149,13 +156,13 @@ __global__ __launch_bounds__(768) void mlp_fwd_kernel(MlpFwdArgs a) {
       const int q = tid + 768 * it, row = q / 24, cc = q % 24;
       v[it] = zero;
       if (q < TOTAL && m0 + row < m_end)
-        v[it] = *reinterpret_cast<const Chunk16*>((PRE ? reinterpret_cast<const T*>(a.pre_a) : X) + (size_t)(m0 + row) * D + cc * CHN);
+        v[it] = *reinterpret_cast<const Chunk16*>((FPRE ? reinterpret_cast<const T*>(a.pre_a) : X) + (size_t)(m0 + row) * D + cc * CHN);
     }
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int q = tid + 768 * it, row = q / 24, cc = q % 24;
       if (q < TOTAL) {
-        if (MODE == MLP_FWD && !PRE && m0 + row < m_end) {
+        if (MODE == MLP_FWD && !FPRE && m0 + row < m_end) {
           const float mean = a.mean[m0 + row], rstd = a.rstd[m0 + row];
           float f[CHN];
           chunk_to_f32<T>(v[it], f);
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(768) void mlp_fwd_kernel(MlpFwdArgs a) {
     compute(sA, s & 1, acc);
   };
 
-  if (PRE) {
+  if (FPRE) {
     // ---- GEMM0: attention branch tail  x_mid = x_in + a Wp^T + bp ; row statistics ; LN2 -> A image of GEMM1 ----
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) step(ks, sXA + ks * SLAB_A, acc1);
@@ -392,7 +399,12 @@ __global__ __launch_bounds__(768) void mlp_fwd_kernel(MlpFwdArgs a) {
             lnacc_g[t] += v[t] * xh[t];
             lnacc_b[t] += v[t];
           }
-          *reinterpret_cast<Chunk16*>(Out + off) = f32_to_chunk<T>(o8);
+          const Chunk16 oc = f32_to_chunk<T>(o8);
+          *reinterpret_cast<Chunk16*>(Out + off) = oc;
+          if (POST) {   // dx rows as the A image of the projection-gradient GEMM (the x panel image is free by now)
+            const int lrow = gm - m0, slab = pc >> 3, slot = pc & 7;
+            *reinterpret_cast<Chunk16*>(sXA + slab * SLAB_A + lrow * ROWB + ((slot ^ ((lrow >> 1) & 7)) << 4)) = oc;
+          }
         }
       }
     }
@@ -416,6 +428,41 @@ __global__ __launch_bounds__(768) void mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll
       for (int k = 0; k < 24; ++k) sres += red[(k * 2 + which) * BN + col];
       atomicAdd((which == 0 ? a.dgamma : a.dbeta) + col, sres);
+    }
+    if (POST) {
+      // ---- GEMM3: da = dx W_proj, plain store (rows >= m_end of the image hold stale finite values: never stored)
+      __syncthreads();   // column-sum scratch (weight buffers) consumed
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc1[i][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) step(S1 + ks, sXA + ks * SLAB_A, acc1);
+      T* __restrict__ Po = reinterpret_cast<T*>(a.post_out);
+#pragma unroll
+      for (int pass = 0; pass < 3; ++pass) {
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+          *reinterpret_cast<f32x4*>(ep + (16 * wm + c) * EP_LD + wn * 48 + 16 * nt + 4 * g) = acc1[nt][pass];
+        __syncthreads();
+#pragma unroll 1
+        for (int i = 0; i < 2; ++i) {
+          const int qd = tid + 768 * i;
+          if (qd < 48 * 24) {
+            const int row = qd / 24, pc = qd % 24;
+            const int gm = m0 + (row >> 4) * 48 + 16 * pass + (row & 15);
+            if (gm < m_end) {
+              float v[8];
+              const f32x4 x0 = *reinterpret_cast<const f32x4*>(ep + row * EP_LD + pc * 8);
+              const f32x4 x1 = *reinterpret_cast<const f32x4*>(ep + row * EP_LD + pc * 8 + 4);
+#pragma unroll
+              for (int t = 0; t < 4; ++t) { v[t] = x0[t]; v[4 + t] = x1[t]; }
+              *reinterpret_cast<Chunk16*>(Po + (size_t)gm * D + pc * 8) = f32_to_chunk<T>(v);
+            }
+          }
+        }
+      }
     }
     return;
   }
@@ -487,6 +534,7 @@ static int mlp_launch(int mode, MlpFwdArgs& a, hipStream_t stream, bool pre = fa
   const int grid = (a.M + a.panel_rows - 1) / a.panel_rows;
   if (mode == MLP_FWD && pre) hipLaunchKernelGGL((mlp_fwd_kernel<bf16, MLP_FWD, true>), dim3(grid), dim3(768), 0, stream, a);
   else if (mode == MLP_FWD) hipLaunchKernelGGL((mlp_fwd_kernel<bf16, MLP_FWD, false>), dim3(grid), dim3(768), 0, stream, a);
+  else if (pre) hipLaunchKernelGGL((mlp_fwd_kernel<bf16, MLP_BWD, true>), dim3(grid), dim3(768), 0, stream, a);
   else hipLaunchKernelGGL((mlp_fwd_kernel<bf16, MLP_BWD, false>), dim3(grid), dim3(768), 0, stream, a);
   VITPE_CHECK_LAUNCH();
 }
@@ -545,4 +593,19 @@ extern "C" int vitpe_block_tail_fwd(int dtype, const void* attn_out, const void*
   a.u_out = u_out; a.h_out = h_out; a.out = out; a.mean_out = mean_out; a.rstd_out = rstd_out;
   a.M = M; a.HID = HID; a.eps = eps_next;
   return mlp_launch(MLP_FWD, a, stream, true);
+}
+
+// Backward mirror of vitpe_block_tail_fwd's fusion: vitpe_mlp_bwd plus the data gradient of the attention projection,
+//   da = dx W_proj   [M,192]  (WpT = attn.proj.weight^T, the transposed shadow), the input of the attention backward.
+extern "C" int vitpe_block_tail_bwd(int dtype, const void* dy, const void* u, const void* W2t, const void* W1t,
+                                    const void* x, const float* mean, const float* rstd, const float* gamma, void* du,
+                                    void* dx, float* dgamma, float* dbeta, const void* WpT, void* da, int M, int D,
+                                    int HID, hipStream_t stream) {
+  VITPE_REQUIRE(dy && u && W2t && W1t && x && mean && rstd && gamma && du && dx && dgamma && dbeta && WpT && da && M >= 0);
+  if (!vitpe_mlp_fwd_supported(dtype, D, HID)) return (int)hipErrorNotSupported;
+  if (M == 0) return 0;
+  MlpFwdArgs a{};
+  a.x = dy; a.gamma = gamma; a.mean = mean; a.rstd = rstd; a.W1 = W2t; a.W2 = W1t; a.u_out = du; a.out = dx;
+  a.u_in = u; a.ln_x = x; a.dgamma = dgamma; a.dbeta = dbeta; a.post_w = WpT; a.post_out = da; a.M = M; a.HID = HID;
+  return mlp_launch(MLP_BWD, a, stream, true);
 }

@@ -347,7 +347,15 @@ class TrainEngine:
             # ---- MLP branch: x_out = xmid + fc2(gelu(fc1(LN2(xmid))))
             self._wgrad(e_dy, lambda: K.gemm_tn(dy, a["h"], G(blk.mlp.fc2.weight), G(blk.mlp.fc2.bias)))
             fc1_wgrad = lambda: K.gemm_tn(du, a["xn2"].view(M, D), G(blk.mlp.fc1.weight), G(blk.mlp.fc1.bias))  # noqa: E731
-            if self.fuse_mlp and self.fuse_ln_bwd:   # gelu' + both data gradients + LayerNorm2 backward + residual
+            tail_done = False
+            if self.fuse_mlp and self.fuse_ln_bwd and self.fuse_tail:   # ... + the projection's data gradient
+                K.block_tail_bwd(dy, a["u"], self.St(blk.mlp.fc2.weight), self.St(blk.mlp.fc1.weight),
+                                 a["xmid"].view(M, D), a["m2"], a["r2"], blk.norm2.weight.data, G(blk.norm2.weight),
+                                 G(blk.norm2.bias), self.St(blk.attn.proj.weight), du=du, out=dmid3.view(M, D),
+                                 da=self.dtmp.view(M, D))
+                self._wgrad(ev(), fc1_wgrad)
+                tail_done = True
+            elif self.fuse_mlp and self.fuse_ln_bwd:   # gelu' + both data gradients + LayerNorm2 backward + residual
                 K.mlp_bwd(dy, a["u"], self.St(blk.mlp.fc2.weight), self.St(blk.mlp.fc1.weight), a["xmid"].view(M, D),
                           a["m2"], a["r2"], blk.norm2.weight.data, G(blk.norm2.weight), G(blk.norm2.bias), du=du,
                           out=dmid3.view(M, D))
@@ -367,7 +375,8 @@ class TrainEngine:
             dm = dmid3.view(M, D)
             e_dm = ev()
             self._wgrad(e_dm, lambda: K.gemm_tn(dm, a["a"].view(M, D), G(blk.attn.proj.weight), G(blk.attn.proj.bias)))
-            K.linear(dm, self.St(blk.attn.proj.weight), None, out=self.dtmp.view(M, D))
+            if not tail_done:
+                K.linear(dm, self.St(blk.attn.proj.weight), None, out=self.dtmp.view(M, D))
             K.fused_attention_bwd(a["xn1"], self.Pk(blk.attn.qkv.weight), self.dtmp, self.H, self.pe,
                                   out=dqkv, **self.pe_grads)
             e_dq = ev()

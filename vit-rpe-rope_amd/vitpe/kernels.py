@@ -179,6 +179,23 @@ def mlp_bwd(dy, u, w2t, w1t, x, mean, rstd, gamma, dgamma, dbeta, du=None, out=N
     return out, du
 
 
+def block_tail_bwd(dy, u, w2t, w1t, x, mean, rstd, gamma, dgamma, dbeta, wpt, du=None, out=None, da=None):
+    """mlp_bwd + da = dx @ proj.weight (wpt = proj.weight^T) in one kernel -> (dx, du, da)."""
+    require_device(dy, u, w2t, w1t, x, mean, rstd, gamma, dgamma, dbeta, wpt, du, out, da)
+    M, D = dy.shape
+    HID = u.shape[1]
+    assert w2t.shape == (HID, D) and w1t.shape == (D, HID) and wpt.shape == (D, D)
+    assert dy.dtype == u.dtype == w2t.dtype == w1t.dtype == x.dtype == wpt.dtype
+    _f32(gamma, "gamma"), _f32(dgamma, "dgamma"), _f32(dbeta, "dbeta")
+    du = du if du is not None else torch.empty_like(u)
+    out = out if out is not None else torch.empty_like(dy)
+    da = da if da is not None else torch.empty_like(dy)
+    check(lib().vitpe_block_tail_bwd(dtype_code(dy.dtype), ptr(dy), ptr(u), ptr(w2t), ptr(w1t), ptr(x), ptr(mean), ptr(rstd),
+                                     ptr(gamma), ptr(du), ptr(out), ptr(dgamma), ptr(dbeta), ptr(wpt), ptr(da), M, D, HID,
+                                     stream_ptr()), "vitpe_block_tail_bwd")
+    return out, du, da
+
+
 class _WgradProblem(ctypes.Structure):   # include/vitpe.h: vitpe_wgrad_problem
     _fields_ = [("dY", ctypes.c_void_p), ("X", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("dbias", ctypes.c_void_p),
                 ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("reserved", ctypes.c_int)]
