@@ -182,8 +182,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
 #pragma unroll
       for (int h = 0; h < 8 / CHN; ++h)
         *reinterpret_cast<Chunk16*>(U + off + h * CHN) = f32_to_chunk<T>(v + h * CHN);
-#pragma unroll
-      for (int t = 0; t < 8; ++t) v[t] = gelu_erf(v[t]);
+      gelu_erf_x8(v);
     }
     if (EPI == EPI_GELU_BWD) {
       const T* U = reinterpret_cast<const T*>(a.U);
@@ -191,8 +190,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs a) {
 #pragma unroll
       for (int h = 0; h < 8 / CHN; ++h)
         chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(U + off + h * CHN), uv + h * CHN);
-#pragma unroll
-      for (int t = 0; t < 8; ++t) v[t] *= gelu_erf_grad(uv[t]);
+      gelu_erf_grad_mul_x8(v, uv);
     }
 #pragma unroll
     for (int h = 0; h < 8 / CHN; ++h)
@@ -461,16 +459,14 @@ void gemm_panel_kernel(GemmPanelArgs a) {
 #pragma unroll
             for (int h = 0; h < 8 / CHN; ++h)
               __builtin_nontemporal_store(f32_to_chunk<T>(v + h * CHN), reinterpret_cast<Chunk16*>(reinterpret_cast<T*>(a.U) + off + h * CHN));
-#pragma unroll
-            for (int t = 0; t < 8; ++t) v[t] = gelu_erf(v[t]);
+            gelu_erf_x8(v);
           }
           if (EPI == EPI_GELU_BWD) {
             float uv[8];
 #pragma unroll
             for (int h = 0; h < 8 / CHN; ++h)
               chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(reinterpret_cast<const T*>(a.U) + off + h * CHN), uv + h * CHN);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) v[t] *= gelu_erf_grad(uv[t]);
+            gelu_erf_grad_mul_x8(v, uv);
           }
 #pragma unroll
           for (int h = 0; h < 8 / CHN; ++h)

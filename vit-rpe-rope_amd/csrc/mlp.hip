@@ -312,8 +312,7 @@ __global__ __launch_bounds__(768) void mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) { v[t] = x0[t] + b0[t]; v[4 + t] = x1[t] + b1v[t]; }
             const Chunk16 uc = f32_to_chunk<T>(v);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) v[t] = gelu_erf(v[t]);
+            gelu_erf_x8(v);
             hc = f32_to_chunk<T>(v);
             if (gm < m_end) {
               __builtin_nontemporal_store(uc, reinterpret_cast<Chunk16*>(Uo + (size_t)gm * HID + gn));
@@ -323,7 +322,8 @@ __global__ __launch_bounds__(768) void mlp_fwd_kernel(MlpFwdArgs a) {
             float uv[8];
             chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(reinterpret_cast<const T*>(a.u_in) + (size_t)min(gm, m_end - 1) * HID + gn), uv);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { v[t] = x0[t] * gelu_erf_grad(uv[t]); v[4 + t] = x1[t] * gelu_erf_grad(uv[4 + t]); }
+            for (int t = 0; t < 4; ++t) { v[t] = x0[t]; v[4 + t] = x1[t]; }
+            gelu_erf_grad_mul_x8(v, uv);
             hc = f32_to_chunk<T>(v);
             if (gm < m_end) *reinterpret_cast<Chunk16*>(Uo + (size_t)gm * HID + gn) = hc;
           }
