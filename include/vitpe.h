@@ -242,6 +242,16 @@ int vitpe_head_bwd(int dtype, const float* dlogits, const float* Wh, const float
                    const float* ws_xhat, const float* ws_yn, const float* ws_rstd, float* ws_dyn,
                    void* dx, float* dWh, float* dbh, float* dgamma, float* dbeta, int B, int Ntok,
                    int D, int Cn, vitpe_stream_t stream);
+/* Training-step fusion of vitpe_head_fwd + vitpe_cross_entropy + vitpe_head_bwd (vit.py:284-285, train.py:113-114
+ * and their autograd) for classes <= 64 (else hipErrorNotSupported): logits, dlogits = (softmax - onehot) *
+ * grad_scale, dx (class row; other rows zero), out2 = [mean loss, #correct] of THIS batch, metric_acc (nullable)
+ * += out2, parameter gradients accumulated.  scratch: 4 zero-initialised floats owned by the caller (batch
+ * totals + arrival counter; the kernel re-arms it, so graph replay needs no memset).                      */
+int vitpe_head_loss(int dtype, const void* x, const float* gamma, const float* beta, const float* Wh,
+                    const float* bh, const long long* labels, float* logits, float* dlogits, float* ws_xhat,
+                    float* ws_yn, float* ws_dyn, void* dx, float* out2, float* metric_acc, float* scratch,
+                    float* dWh, float* dbh, float* dgamma, float* dbeta, int B, int Ntok, int D, int Cn,
+                    float eps, float grad_scale, vitpe_stream_t stream);
 
 /* ---- optimizer + weight shadows (train.py:116,195) ------------------------------------------
  * hp (device, 16 floats): [0]=lr [1]=beta1 [2]=beta2 [3]=eps [4]=weight_decay [5]=step

@@ -715,3 +715,37 @@ def test_unfold_u8_gather_normalise_unfold(K, C, S, p, name):
     from vitpe._lib import VitpeError
     with pytest.raises(VitpeError):
         K.unfold_u8(data.float().cuda(), idx.cuda(), md, sd, p, torch.float32)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("B,N,D,Cn", [(37, 65, 192, 10), (5, 17, 96, 3), (9, 65, 192, 64)])
+def test_fused_head_loss_equals_the_three_kernels(K, dt, B, N, D, Cn):
+    """vitpe_head_loss == vitpe_head_fwd + vitpe_cross_entropy + vitpe_head_bwd (and replays: the scratch re-arms)."""
+    x = dev(rnd(B, N, D, seed=1), DT[dt])
+    g, b = dev(1 + 0.1 * rnd(D, seed=2)), dev(0.1 * rnd(D, seed=3))
+    wh, bh = dev(rnd(Cn, D, seed=4, scale=0.2)), dev(0.1 * rnd(Cn, seed=5))
+    labels = torch.randint(0, Cn, (B,), generator=torch.Generator().manual_seed(6)).cuda()
+    z = lambda *s: torch.zeros(*s, device="cuda")  # noqa: E731
+    # reference: the three kernels
+    lg, ws = K.head_fwd(x, g, b, wh, bh, save=True)
+    out2, dlog = K.cross_entropy(lg, labels)
+    gw, gb, gg, gbt = z(Cn, D), z(Cn), z(D), z(D)
+    dx = K.head_bwd(dlog, wh, g, ws, DT[dt], N, gw, gb, gg, gbt)
+    # fused
+    lg2, dlog2, dx2 = z(B, Cn), z(B, Cn), torch.full((B, N, D), 7.0, device="cuda").to(DT[dt])
+    ws2, dyn2 = (z(B, D), z(B, D), z(B)), z(B, D)
+    o2, macc, scratch = z(2), z(2), z(4)
+    gw2, gb2, gg2, gbt2 = z(Cn, D), z(Cn), z(D), z(D)
+    for rep in range(2):
+        K.head_loss(x, g, b, wh, bh, labels, lg2, dlog2, ws2, dyn2, dx2, o2, macc, scratch, gw2, gb2, gg2, gbt2)
+    assert rel_err(lg2.cpu(), lg.cpu()) < 1e-6 and rel_err(dlog2.cpu(), dlog.cpu()) < 1e-5
+    assert rel_err(dx2.float().cpu(), dx.float().cpu()) < (1e-5 if dt == "f32" else 1e-2)
+    assert abs(float(o2[0]) - float(out2[0])) < 1e-5 and float(o2[1]) == float(out2[1])
+    assert abs(float(macc[0]) - 2 * float(out2[0])) < 2e-5 and float(macc[1]) == 2 * float(out2[1])
+    assert float(scratch.abs().sum()) == 0.0                      # re-armed
+    for a2, a1 in ((gw2, gw), (gb2, gb), (gg2, gg), (gbt2, gbt)):
+        assert rel_err(a2.cpu(), 2 * a1.cpu()) < 1e-5            # accumulated twice
+    from vitpe._lib import VitpeError
+    with pytest.raises(VitpeError):
+        K.head_loss(x, g, b, z(65, D), z(65), labels, z(B, 65), z(B, 65), ws2, dyn2, dx2, o2, macc, scratch, z(65, D), z(65),
+                    gg2, gbt2)

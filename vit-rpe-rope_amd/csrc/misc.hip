@@ -214,6 +214,102 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
   if (threadIdx.x == 0) { out[0] = sl[0] / (float)B; out[1] = sc[0]; }
 }
 
+// Training-step fusion of the three kernels above and below (classes <= 64): per image (one wave) the class row's
+// LayerNorm, the logits, softmax cross-entropy (train.py:113: mean over the batch), accuracy count, dlogits, and
+// the head's data gradient through the LayerNorm (dx row 0; rows 1.. zero) -- so the [B,C] logits never make a
+// round trip and three launches become one.  Batch totals: every wave adds its (loss/B, correct) into scratch[0..1]
+// and bumps scratch[2]; the last wave publishes out2 = totals, adds them to metric_acc and re-arms the scratch
+// (replay-safe).  head_bwd_params_kernel still follows for the parameter gradients.
+template <typename T>
+__global__ __launch_bounds__(256) void head_loss_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ Wh,
+                                                        const float* __restrict__ bh, const long long* __restrict__ labels,
+                                                        float* __restrict__ logits, float* __restrict__ dlogits,
+                                                        float* __restrict__ ws_xhat, float* __restrict__ ws_yn,
+                                                        float* __restrict__ ws_dyn, T* __restrict__ dx, float* out2,
+                                                        float* metric_acc, float* scratch, int B, int Ntok, int D, int Cn,
+                                                        float eps, float gscale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invD = 1.0f / (float)D;
+  for (int b = blockIdx.x * 4 + wave; b < B; b += gridDim.x * 4) {
+    const T* row = x + (size_t)b * Ntok * D;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += to_f32(row[d]);
+    const float mean = wave_sum(s) * invD;
+    float s2 = 0.f;
+    for (int d = lane; d < D; d += 64) { const float t = to_f32(row[d]) - mean; s2 += t * t; }
+    const float rstd = 1.0f / sqrtf(wave_sum(s2) * invD + eps);
+    for (int d = lane; d < D; d += 64) {
+      const float xh = (to_f32(row[d]) - mean) * rstd;
+      ws_xhat[(size_t)b * D + d] = xh;
+      ws_yn[(size_t)b * D + d] = xh * gamma[d] + beta[d];
+    }
+    float z = -3.0e38f;   // lane k < Cn holds logit k
+    for (int cI = 0; cI < Cn; ++cI) {
+      float acc = 0.f;
+      for (int d = lane; d < D; d += 64) {
+        const float xh = (to_f32(row[d]) - mean) * rstd;
+        acc += (xh * gamma[d] + beta[d]) * Wh[(size_t)cI * D + d];
+      }
+      acc = wave_sum(acc) + bh[cI];
+      if (lane == cI) z = acc;
+    }
+    if (lane < Cn) logits[(size_t)b * Cn + lane] = z;
+    float m = z;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    int am = (lane < Cn && z == m) ? lane : 1 << 20;   // first index of the maximum (torch.max semantics)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) am = min(am, __shfl_xor(am, o, 64));
+    const float e = lane < Cn ? expf(z - m) : 0.f;
+    const float se = wave_sum(e);
+    const int y = (int)labels[b];
+    const float zy = __shfl(z, y, 64);
+    const float dl = lane < Cn ? (e * (1.0f / se) - (lane == y ? 1.f : 0.f)) * gscale : 0.f;
+    if (lane < Cn) dlogits[(size_t)b * Cn + lane] = dl;
+    // data gradient: dyn = dlogits @ Wh, LayerNorm backward of the class row
+    float t1 = 0.f, t2 = 0.f;
+    for (int d = lane; d < D; d += 64) {
+      float dyn = 0.f;
+      for (int k = 0; k < Cn; ++k) dyn += __shfl(dl, k, 64) * Wh[(size_t)k * D + d];
+      ws_dyn[(size_t)b * D + d] = dyn;
+      const float gv = dyn * gamma[d];
+      t1 += gv;
+      t2 += gv * ((to_f32(row[d]) - mean) * rstd);
+    }
+    t1 = wave_sum(t1) * invD;
+    t2 = wave_sum(t2) * invD;
+    T* drow = dx + (size_t)b * Ntok * D;
+    for (int d = lane; d < D; d += 64) {
+      float dyn = 0.f;
+      for (int k = 0; k < Cn; ++k) dyn += __shfl(dl, k, 64) * Wh[(size_t)k * D + d];
+      const float gv = dyn * gamma[d];
+      drow[d] = from_f32<T>(rstd * (gv - t1 - ((to_f32(row[d]) - mean) * rstd) * t2));
+    }
+    if (D % CH<T>::n == 0) {   // rows 1.. are zero: 16-B stores
+      const Chunk16 z16 = {0u, 0u, 0u, 0u};
+      for (size_t q = D / CH<T>::n + lane; q < (size_t)Ntok * D / CH<T>::n; q += 64)
+        *reinterpret_cast<Chunk16*>(drow + q * CH<T>::n) = z16;
+    } else {
+      for (size_t q = D + lane; q < (size_t)Ntok * D; q += 64) drow[q] = from_f32<T>(0.f);
+    }
+    if (lane == 0) {
+      atomicAdd(scratch + 0, ((m + logf(se)) - zy) / (float)B);
+      atomicAdd(scratch + 1, am == y ? 1.f : 0.f);
+      __threadfence();
+      const unsigned done = atomicAdd(reinterpret_cast<unsigned*>(scratch + 2), 1u);
+      if (done == (unsigned)B - 1) {   // last image of the batch: publish, accumulate, re-arm
+        __threadfence();
+        const float l = atomicExch(scratch + 0, 0.f), cr = atomicExch(scratch + 1, 0.f);
+        atomicExch(reinterpret_cast<unsigned*>(scratch + 2), 0u);
+        out2[0] = l;
+        out2[1] = cr;
+        if (metric_acc != nullptr) { metric_acc[0] += l; metric_acc[1] += cr; }
+      }
+    }
+  }
+}
+
 // head backward, stage 1 (one wave per image): dyn = dlogits @ Wh ; LN backward of the class row;
 // dx row 0 written, rows 1.. zeroed.  ws_dyn [B,D] kept for stage 2.
 template <typename T>
@@ -241,7 +337,13 @@ __global__ __launch_bounds__(256) void head_bwd_rows_kernel(const float* __restr
       const float gv = ws_dyn[(size_t)b * D + d] * gamma[d];
       drow[d] = from_f32<T>(rstd * (gv - s1 - ws_xhat[(size_t)b * D + d] * s2));
     }
-    for (size_t q = D + lane; q < (size_t)Ntok * D; q += 64) drow[q] = from_f32<T>(0.f);
+    if (D % CH<T>::n == 0) {   // rows 1.. are zero: 16-B stores
+      const Chunk16 z16 = {0u, 0u, 0u, 0u};
+      for (size_t q = D / CH<T>::n + lane; q < (size_t)Ntok * D / CH<T>::n; q += 64)
+        *reinterpret_cast<Chunk16*>(drow + q * CH<T>::n) = z16;
+    } else {
+      for (size_t q = D + lane; q < (size_t)Ntok * D; q += 64) drow[q] = from_f32<T>(0.f);
+    }
   }
 }
 // stage 2: column sums over the batch, split over batch chunks (blockIdx.y) + fp32 atomics.
@@ -511,6 +613,30 @@ extern "C" int vitpe_head_bwd(int dtype, const float* dlogits, const float* Wh, 
   else
     hipLaunchKernelGGL(head_bwd_rows_kernel<float>, dim3(blocks), dim3(256), 0, st, dlogits, Wh, gamma, ws_xhat,
                        ws_rstd, ws_dyn, (float*)dx, B, Ntok, D, Cn);
+  int e = (int)hipGetLastError();
+  if (e) return e;
+  hipLaunchKernelGGL(head_bwd_params_kernel, dim3((Cn * D + Cn + D + 255) / 256, (B + 31) / 32), dim3(256), 0, st,
+                     dlogits, ws_yn, ws_dyn, ws_xhat, dWh, dbh, dgamma, dbeta, B, D, Cn, 32);
+  VITPE_CHECK_LAUNCH();
+}
+extern "C" int vitpe_head_loss(int dtype, const void* x, const float* gamma, const float* beta, const float* Wh,
+                               const float* bh, const long long* labels, float* logits, float* dlogits, float* ws_xhat,
+                               float* ws_yn, float* ws_dyn, void* dx, float* out2, float* metric_acc, float* scratch,
+                               float* dWh, float* dbh, float* dgamma, float* dbeta, int B, int Ntok, int D, int Cn,
+                               float eps, float grad_scale, hipStream_t st) {
+  VITPE_REQUIRE(x && gamma && beta && Wh && bh && labels && logits && dlogits && ws_xhat && ws_yn && ws_dyn && dx && out2 &&
+                scratch && dWh && dbh && dgamma && dbeta && B >= 0 && (dtype == 0 || dtype == 1));
+  if (Cn < 1 || Cn > 64) return (int)hipErrorNotSupported;
+  if (B == 0) return 0;
+  const int blocks = min((B + 3) / 4, 1024);
+  if (dtype == 1)
+    hipLaunchKernelGGL(head_loss_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)x, gamma, beta, Wh, bh, labels,
+                       logits, dlogits, ws_xhat, ws_yn, ws_dyn, (bf16*)dx, out2, metric_acc, scratch, B, Ntok, D, Cn, eps,
+                       grad_scale);
+  else
+    hipLaunchKernelGGL(head_loss_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, gamma, beta, Wh, bh, labels,
+                       logits, dlogits, ws_xhat, ws_yn, ws_dyn, (float*)dx, out2, metric_acc, scratch, B, Ntok, D, Cn, eps,
+                       grad_scale);
   int e = (int)hipGetLastError();
   if (e) return e;
   hipLaunchKernelGGL(head_bwd_params_kernel, dim3((Cn * D + Cn + D + 255) / 256, (B + 31) / 32), dim3(256), 0, st,

@@ -178,6 +178,8 @@ class TrainEngine:
         self.logits, self.dlogits = f(B, self.Cn), f(B, self.Cn)
         self.out2 = f(2)
         self.metric_acc = torch.zeros(2, dtype=torch.float32, device=dev)  # [sum of mean losses, #correct]
+        self.head_scratch = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.fuse_head = self.Cn <= 64 and __import__("os").environ.get("VITPE_FUSE_HEAD", "1") == "1"
         self.head_ws = (f(B, D), f(B, D), f(B))
         self.ws_dyn = f(B, D)
         # Gradient tensors read by the weight-gradient GEMMs get per-layer buffers (dy = d x_out, dmid = d x_mid,
@@ -216,7 +218,7 @@ class TrainEngine:
             self.pe_grads["dfreqs"] = self.Gr(pe.freqs)
 
     # ---------------------------------------------------------------- forward / backward
-    def _forward(self):
+    def _forward(self, head=True):
         mdl, B, N, D, M = self.model, self.B, self.N, self.D, self.M
         if self.dataset is not None:   # resident uint8 dataset: gather + ToTensor + Normalize inside the unfold
             K.unfold_u8(self.dataset.images, self.batch_idx, self.dataset.mean, self.dataset.std, self.p, self.T,
@@ -275,10 +277,21 @@ class TrainEngine:
                      u=a["u"], out=a["h"])
             K.linear(a["h"], self.Sh(blk.mlp.fc2.weight), blk.mlp.fc2.bias.data, epi=L.EPI_BIAS_RESID,
                      resid=a["xmid"].view(M, D), out=self.x[l + 1].view(M, D))
-        K.head_fwd(self.x[-1], mdl.norm.weight.data, mdl.norm.bias.data, mdl.head.weight.data, mdl.head.bias.data,
-                   mdl.norm.eps, save=True, logits=self.logits, ws=self.head_ws)
+        if head:
+            K.head_fwd(self.x[-1], mdl.norm.weight.data, mdl.norm.bias.data, mdl.head.weight.data, mdl.head.bias.data,
+                       mdl.norm.eps, save=True, logits=self.logits, ws=self.head_ws)
+
+    def _fwd_train(self):
+        self._forward(head=not self.fuse_head)
 
     def _loss(self):
+        if self.fuse_head:   # final LayerNorm + head + CE + accuracy + dlogits + the head's backward: one launch pair
+            mdl, G = self.model, self.Gr
+            K.head_loss(self.x[-1], mdl.norm.weight.data, mdl.norm.bias.data, mdl.head.weight.data, mdl.head.bias.data,
+                        self.labels, self.logits, self.dlogits, self.head_ws, self.ws_dyn, self.dx_out[self.Lyr], self.out2,
+                        self.metric_acc, self.head_scratch, G(mdl.head.weight), G(mdl.head.bias), G(mdl.norm.weight),
+                        G(mdl.norm.bias), eps=mdl.norm.eps, grad_scale=1.0 / self.B)
+            return
         K.cross_entropy(self.logits, self.labels, grad_scale=1.0 / self.B, dlogits=self.dlogits, out2=self.out2)
         self.metric_acc.add_(self.out2)
 
@@ -334,7 +347,7 @@ class TrainEngine:
             lo = self.split_layer
         elif part == "lower":
             hi = self.split_layer - 1
-        if part != "lower":
+        if part != "lower" and not self.fuse_head:
             dxL = self.dx_out[self.Lyr]
             K.head_bwd(self.dlogits, mdl.head.weight.data, mdl.norm.weight.data, self.head_ws, self.T, N,
                        G(mdl.head.weight), G(mdl.head.bias), G(mdl.norm.weight), G(mdl.norm.bias), dx=dxL,
@@ -424,7 +437,7 @@ class TrainEngine:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(2):
-                self._forward(); self._loss(); self._backward(); self._optimizer()
+                self._fwd_train(); self._loss(); self._backward(); self._optimizer()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         for t, c in zip((self.flat_p, self.flat_m, self.flat_v, self.hp, self.metric_acc), snap):
@@ -435,7 +448,7 @@ class TrainEngine:
         # thread_local: a communicator watchdog thread touching the device must not invalidate the capture
         self.graph_fb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_fb, capture_error_mode="thread_local"):
-            self._forward(); self._loss()
+            self._fwd_train(); self._loss()
             if self.world == 1:
                 self._backward(); self._optimizer()
             elif self.overlap_comm:
@@ -520,12 +533,12 @@ class TrainEngine:
                     self._allreduce()
                 self.graph_opt.replay()
         else:
-            self._forward(); self._loss(); self._backward(); self._allreduce(); self._optimizer()
+            self._fwd_train(); self._loss(); self._backward(); self._allreduce(); self._optimizer()
         self.steps_done += 1
 
     def forward_backward(self):
         """forward + loss + backward on the resident batch without the optimizer (tests / parity)."""
-        self._forward(); self._loss(); self._backward()
+        self._fwd_train(); self._loss(); self._backward()
 
     def forward_only(self, images: torch.Tensor) -> torch.Tensor:
         self.images.copy_(images)

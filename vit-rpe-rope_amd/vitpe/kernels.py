@@ -505,6 +505,22 @@ def head_bwd(dlogits, wh, gamma, ws, dtype, Ntok, dwh, dbh, dgamma, dbeta, dx=No
     return dx
 
 
+def head_loss(x, gamma, beta, wh, bh, labels, logits, dlogits, ws, ws_dyn, dx, out2, metric_acc, scratch, dwh, dbh,
+              dgamma, dbeta, eps=1e-5, grad_scale=None):
+    """head_fwd + cross_entropy + head_bwd in one launch pair (classes <= 64): fills logits / dlogits / dx / out2,
+    adds out2 to metric_acc, accumulates the head's parameter gradients.  ws = (xhat, yn, rstd) work buffers."""
+    require_device(x, gamma, beta, wh, bh, labels, logits, dlogits, ws[0], ws[1], ws_dyn, dx, out2, metric_acc, scratch, dwh,
+                   dbh, dgamma, dbeta)
+    B, Ntok, D = x.shape
+    Cn = wh.shape[0]
+    assert labels.dtype == torch.int64 and scratch.numel() >= 4
+    gs = (1.0 / B) if grad_scale is None else grad_scale
+    check(lib().vitpe_head_loss(dtype_code(x.dtype), ptr(x), ptr(gamma), ptr(beta), ptr(wh), ptr(bh), ptr(labels), ptr(logits),
+                                ptr(dlogits), ptr(ws[0]), ptr(ws[1]), ptr(ws_dyn), ptr(dx), ptr(out2), ptr(metric_acc),
+                                ptr(scratch), ptr(dwh), ptr(dbh), ptr(dgamma), ptr(dbeta), B, Ntok, D, Cn, float(eps),
+                                float(gs), stream_ptr()), "vitpe_head_loss")
+
+
 # ---- optimizer / shadows --------------------------------------------------------------------
 def adamw_step(p, g, m, v, hp, shadow_bf16=None, zero_grad=True):
     require_device(p, g, m, v, hp, shadow_bf16)
