@@ -179,7 +179,9 @@ class TrainEngine:
         self.out2 = f(2)
         self.metric_acc = torch.zeros(2, dtype=torch.float32, device=dev)  # [sum of mean losses, #correct]
         self.head_scratch = torch.zeros(4, dtype=torch.float32, device=dev)
-        self.fuse_head = self.Cn <= 64 and __import__("os").environ.get("VITPE_FUSE_HEAD", "1") == "1"
+        # one-launch head + CE + head backward (vitpe_head_loss): measured 45 us against 40 us for the three small
+        # kernels it replaces (one wave per image is a long serial chain) -- off unless VITPE_FUSE_HEAD=1
+        self.fuse_head = self.Cn <= 64 and __import__("os").environ.get("VITPE_FUSE_HEAD", "0") == "1"
         self.head_ws = (f(B, D), f(B, D), f(B))
         self.ws_dyn = f(B, D)
         # Gradient tensors read by the weight-gradient GEMMs get per-layer buffers (dy = d x_out, dmid = d x_mid,
