@@ -46,9 +46,11 @@ struct WgArgs {
   int nprob, total_units, units_per_wg;
   int use_table;   // 1: workgroup i runs table[i] = (problem << 20 | block << 8 | row range), 0xFFFFFFFF = idle
   int nranges;     // row ranges per block in table mode
+  unsigned long long* census;   // CENSUS build only (vitpe_debug_wgrad_census): s_memtime stamps
   WgProb p[WG_MAXPROB];
   unsigned table[WG_TABLE];
 };
+constexpr int WG_CENSUS_STAGES = 24, WG_CENSUS_SLOTS = 4;
 
 template <typename T> struct WgLayout;
 template <> struct WgLayout<bf16> {
@@ -82,7 +84,7 @@ template <> struct WgLayout<float> {  // exact-fp32 parity mode: padded rows, sc
   }
 };
 
-template <typename T>
+template <typename T, bool CENSUS>
 __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
   using LY = WgLayout<T>;
   constexpr int RPS = 128 / (int)sizeof(T);  // token rows per stage: 64 bf16 / 32 fp32
@@ -210,9 +212,16 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
   decode(u0, cur);
   gload(cur);
   clear();
+  // CENSUS: lane 0 of every wave stamps the shader clock of the first 24 stages: 0 stage stored, 2 next loads
+  // issued, 1 barrier passed, 3 MFMAs done
+  auto stamp = [&](int u, int slot) {
+    if (CENSUS && lane == 0 && u - u0 < WG_CENSUS_STAGES)
+      a.census[(((size_t)blockIdx.x * 12 + wave) * WG_CENSUS_STAGES + (u - u0)) * WG_CENSUS_SLOTS + slot] = __builtin_amdgcn_s_memtime();
+  };
   for (int u = u0; u < uend; ++u) {
     const int buf = (u - u0) & 1;
     sstore(buf);
+    stamp(u, 0);
     nxt = cur;
     bool flush_now = (u + 1 == uend);
     if (u + 1 < uend) {
@@ -220,9 +229,12 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
       else { decode(u + 1, nxt); flush_now = true; }
       gload(nxt);  // in flight under this stage's MFMAs
     }
+    stamp(u, 2);
     __syncthreads();
+    stamp(u, 1);
     const bool bias = (cur.dbias != nullptr) && cur.k0 == 0 && wk == 0;
     compute(buf, bias);
+    stamp(u, 3);
     if (flush_now) flush(cur, bias);
     cur = nxt;
   }
@@ -251,11 +263,26 @@ static int wgrad_cu_count() {
   return n;
 }
 
+static int wgrad_group_launch(int dtype, const void* problems, int nprob, unsigned long long* census, hipStream_t stream);
+
 extern "C" int vitpe_wgrad_group(int dtype, const void* problems, int nprob, hipStream_t stream) {
+  return wgrad_group_launch(dtype, problems, nprob, nullptr, stream);
+}
+
+// debug: the same launch (bf16) with per-wave s_memtime stamps of the first 24 stages of every workgroup:
+// census[((wg * 12 + wave) * 24 + stage) * 4 + slot], >= grid * 12 * 24 * 4 entries (tools/census_wgrad.py)
+extern "C" int vitpe_debug_wgrad_census(int dtype, const void* problems, int nprob, unsigned long long* census,
+                                        hipStream_t stream) {
+  VITPE_REQUIRE(census != nullptr && dtype == 1);
+  return wgrad_group_launch(dtype, problems, nprob, census, stream);
+}
+
+static int wgrad_group_launch(int dtype, const void* problems, int nprob, unsigned long long* census, hipStream_t stream) {
   VITPE_REQUIRE(problems && nprob >= 0 && nprob <= WG_MAXPROB && (dtype == 0 || dtype == 1));
   const vitpe_wgrad_problem_abi* pr = reinterpret_cast<const vitpe_wgrad_problem_abi*>(problems);
   const int RPS = dtype == 1 ? 64 : 32, CHN = dtype == 1 ? 8 : 4;
   WgArgs a{};
+  a.census = census;
   int units = 0, np = 0;
   for (int i = 0; i < nprob; ++i) {
     const vitpe_wgrad_problem_abi& p = pr[i];
@@ -318,7 +345,8 @@ extern "C" int vitpe_wgrad_group(int dtype, const void* problems, int nprob, hip
     a.units_per_wg = (units + wgs - 1) / wgs;
     grid = (units + a.units_per_wg - 1) / a.units_per_wg;
   }
-  if (dtype == 1) hipLaunchKernelGGL(wgrad_group_kernel<bf16>, dim3(grid), dim3(768), 0, stream, a);
-  else hipLaunchKernelGGL(wgrad_group_kernel<float>, dim3(grid), dim3(768), 0, stream, a);
+  if (census != nullptr) hipLaunchKernelGGL((wgrad_group_kernel<bf16, true>), dim3(grid), dim3(768), 0, stream, a);
+  else if (dtype == 1) hipLaunchKernelGGL((wgrad_group_kernel<bf16, false>), dim3(grid), dim3(768), 0, stream, a);
+  else hipLaunchKernelGGL((wgrad_group_kernel<float, false>), dim3(grid), dim3(768), 0, stream, a);
   VITPE_CHECK_LAUNCH();
 }
