@@ -35,7 +35,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=512, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 512; 64 for --config imnet)")
+    ap.add_argument("--config", default="cifar", choices=["cifar", "imnet"],
+                    help="cifar = BASELINE configs[1] (the headline line); imnet = configs[4] geometry (224/16, d=768, L=12, "
+                         "H=12: qkv Linear + attention-core kernels), an extra measurement")
     ap.add_argument("--pos_encoding", default="rope-axial")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -44,10 +47,27 @@ def parse():
 
 
 def time_attention_kernel(eng, iters=100):
-    """Average launch duration of the fused attention forward kernel (layer 0 operands of the
+    """Average launch duration of the attention forward / backward kernel (layer 0 operands of the
     engine), HIP events on the stream the kernel is launched on (torch's current stream)."""
     from vitpe import kernels as K
     blk, a = eng.model.blocks[0], eng.act[0]
+    if not eng.attn_fused:
+        call = lambda: K.attention_core_fwd(eng.qkv_l[0], eng.H, eng.pe, out=a["a"])  # noqa: E731
+        callb = lambda: K.attention_core_bwd(eng.qkv_l[0], eng.dtmp, eng.H, eng.pe, out=eng.dqkv_l[0], **eng.pe_grads)  # noqa: E731
+        times = []
+        for fn in (call, callb):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1) / iters)
+        eng.flat_g.zero_()
+        return times[0], times[1]
     call = lambda: K.fused_attention_fwd(a["xn1"], eng.Pk(blk.attn.qkv.weight), eng.H, eng.pe, out=a["a"])  # noqa: E731
     for _ in range(10):
         call()
@@ -134,17 +154,17 @@ def committed_pmc(kernel="attn_fwd_kernel"):
         return None
 
 
-def cpu_baseline(pos_encoding, steps=20, warmup=2, bs=128):
+def cpu_baseline(pos_encoding, steps=60, warmup=2, bs=128, cfg_kw=None, img=32):
     """The CPU oracle's train step (fp32 eager torch ops, same op sequence as the reference) on
     the host cores of this box.  Baseline only; bounded to ~10-30 s."""
     from oracle import vit_oracle as O
     # one GPU's share of the host is 16 cores; torch's default (all 256 logical CPUs of the node) oversubscribes
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    cfg = O.VitConfig(pos_encoding=pos_encoding)
+    cfg = O.VitConfig(pos_encoding=pos_encoding, **(cfg_kw or {}))
     params = O.init_params(cfg, seed=0)
     st = O.AdamWState()
     g = torch.Generator().manual_seed(1234)
-    images = torch.randn(bs, 3, 32, 32, generator=g)
+    images = torch.randn(bs, 3, img, img, generator=g)
     labels = torch.randint(0, 10, (bs,), generator=g)
     for _ in range(warmup):
         O.train_step(cfg, params, st, images, labels)
@@ -177,13 +197,17 @@ def main():
     from vitpe.vit import VisionTransformer
 
     torch.manual_seed(0)
-    model = VisionTransformer(img_size=32, patch_size=4, in_chans=3, num_classes=10, embed_dim=192, depth=6,
-                              num_heads=6, pos_encoding=args.pos_encoding, rope_theta=100.0).to(dev)
+    imnet = args.config == "imnet"
+    geom = dict(img_size=224, patch_size=16, embed_dim=768, depth=12, num_heads=12) if imnet else \
+        dict(img_size=32, patch_size=4, embed_dim=192, depth=6, num_heads=6)
+    args.batch = args.batch or (64 if imnet else 512)
+    img = geom["img_size"]
+    model = VisionTransformer(in_chans=3, num_classes=10, pos_encoding=args.pos_encoding, rope_theta=100.0, **geom).to(dev)
     T = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     eng = TrainEngine(model, args.batch, compute_dtype=T, use_graph=not args.no_graph)
     eng.broadcast_parameters(0)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    eng.images.copy_(torch.randn(args.batch, 3, 32, 32, generator=g, device=dev))
+    eng.images.copy_(torch.randn(args.batch, 3, img, img, generator=g, device=dev))
     g2 = torch.Generator(device=dev).manual_seed(4321 + rank)
     eng.labels.copy_(torch.randint(0, 10, (args.batch,), generator=g2, device=dev))
 
@@ -212,23 +236,33 @@ def main():
             pm = committed_pmc(key)
             o["traffic"] = pm["hbm_bytes_per_launch"] if pm else None
     if rank == 0:
-        flops = ATTN_FWD_FLOP_PER_IMG_LAYER * args.batch
+        if imnet:   # attention core only: QK^T + AV of 12 heads, N = 197, hd = 64 (the projection is a separate GEMM here)
+            n_tok, hd, heads = eng.N, eng.D // eng.H, eng.H
+            flops = 2 * 2 * n_tok * n_tok * hd * heads * args.batch
+            attn_bytes = 4 * n_tok * eng.D * 2 * args.batch          # q, k, v in + out, bf16
+        else:
+            flops = ATTN_FWD_FLOP_PER_IMG_LAYER * args.batch
+            attn_bytes = ATTN_FWD_BYTES_PER_IMG_LAYER * args.batch
         achieved = flops / (fwd_ms * 1e-3) / 1e12
-        pmc = committed_pmc() if (args.batch == 512 and args.dtype == "bf16") else None
+        pmc = committed_pmc() if (args.batch == 512 and args.dtype == "bf16" and not imnet) else None
         line = {
-            "metric": "train images/sec, CIFAR-10 ViT d=192 L=6 H=6",
+            "metric": ("train images/sec, ImageNet-shaped ViT-B/16 d=768 L=12 H=12 (BASELINE config 5 geometry)" if imnet
+                       else "train images/sec, CIFAR-10 ViT d=192 L=6 H=6"),
             "value": round(world * args.batch * args.steps / elapsed, 1),
             "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"CIFAR-10-shaped 32x32 patch4 ViT d=192 L=6 H=6, --pos_encoding {args.pos_encoding} "
+            "config": {"workload": (f"ImageNet-shaped 224x224 patch16 ViT d=768 L=12 H=12, 10 classes" if imnet else
+                                    f"CIFAR-10-shaped 32x32 patch4 ViT d=192 L=6 H=6") +
+                                   f", --pos_encoding {args.pos_encoding} "
                                    f"theta=100, {args.dtype}, full train step (fwd+CE+bwd+AdamW), random-init weights",
                        "per_gpu_batch": args.batch, "global_batch": world * args.batch,
                        "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
                        "final_loss_mean": round(loss / max(args.steps + args.warmup, 1), 4)},
-            "roofline": {"kernel": "attn_fwd_kernel (fused QKV-project+RoPE+QK^T+softmax+AV)", "bound": "mfma",
+            "roofline": {"kernel": ("attn_core_fwd_kernel (RoPE+QK^T+softmax+AV per (image, head) on a qkv buffer)" if imnet else
+                                    "attn_fwd_kernel (fused QKV-project+RoPE+QK^T+softmax+AV)"), "bound": "mfma",
                          "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
                          "traffic": (pmc["hbm_bytes_per_launch"] if pmc else None),
@@ -238,14 +272,15 @@ def main():
                                                        (pmc["SQ_BUSY_CYCLES"] / 32), 3) if pmc else None),
                          "launch_ms": round(fwd_ms, 5),
                          "algorithmic_flop_per_launch": flops,
-                         "algorithmic_bytes_per_launch": ATTN_FWD_BYTES_PER_IMG_LAYER * args.batch,
+                         "algorithmic_bytes_per_launch": attn_bytes,
                          "bwd_launch_ms": round(bwd_ms, 5),
                          "bwd_achieved_tflops": round(2 * flops / (bwd_ms * 1e-3) / 1e12, 2)},
         }
         if others:
             line["other_kernels"] = others
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.pos_encoding)
+            line["cpu_baseline"] = (cpu_baseline(args.pos_encoding, steps=2, warmup=1, bs=8, cfg_kw=geom, img=img) if imnet
+                                    else cpu_baseline(args.pos_encoding))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

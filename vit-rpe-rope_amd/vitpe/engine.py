@@ -65,8 +65,13 @@ class TrainEngine:
         self.hid = m.blocks[0].mlp.fc1.weight.shape[0]
         self.Cn = m.num_classes
         self.M = self.B * self.N
-        if not K.fused_attention_supported(self.T, self.N, self.D, self.D // self.H):
-            raise L.VitpeError(f"fused attention kernel does not support N={self.N}, D={self.D}, hd={self.D // self.H}")
+        # CIFAR geometry: fused attention kernels (qkv never leaves the chip).  Other geometries (224/16, d=768, H=12:
+        # N=197, hd=64): qkv Linear into a per-layer buffer + the per-(image, head) attention core.
+        self.attn_fused = K.fused_attention_supported(self.T, self.N, self.D, self.D // self.H)
+        if not self.attn_fused and not K.attention_core_supported(self.T, self.N, self.D // self.H):
+            raise L.VitpeError(f"no attention kernel for N={self.N}, D={self.D}, hd={self.D // self.H}")
+        if not self.attn_fused:   # the LayerNorm / MLP fusions hang off the fused attention kernels' geometry
+            self.fuse_ln = self.fuse_ln_bwd = self.fuse_mlp = False
         self._build_flat(lr, weight_decay, betas, eps)
         self._build_buffers()
         # gradient exchange in two buckets so the first overlaps the lower half of the backward pass:
@@ -118,7 +123,8 @@ class TrainEngine:
             for w in (blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight):
                 self._gemm_weights.append(w)
                 spans.append((w, 0, add(w, 0)))
-            spans.append((blk.attn.qkv.weight, 1, add(blk.attn.qkv.weight, 1)))
+            if self.attn_fused:
+                spans.append((blk.attn.qkv.weight, 1, add(blk.attn.qkv.weight, 1)))
         self._shadow_flat = torch.empty(off, dtype=self.T, device=self.dev)
         for w, kind, o in spans:
             R, C = w.shape
@@ -192,6 +198,7 @@ class TrainEngine:
         self.dx_mid = [e(B, N, D) for _ in range(self.Lyr)]
         self.du_l = [e(M, self.hid) for _ in range(self.Lyr)]
         self.dqkv_l = [e(B, N, 3 * D) for _ in range(self.Lyr)]
+        self.qkv_l = [] if self.attn_fused else [e(B, N, 3 * D) for _ in range(self.Lyr)]
         self.dqkv, self.du = self.dqkv_l[0], self.du_l[0]          # (bench.py times the kernels on these)
         self.side = torch.cuda.Stream(device=dev)
         self.dataset, self.batch_idx = None, None
@@ -270,7 +277,11 @@ class TrainEngine:
                 continue
             K.layernorm_fwd(xin, blk.norm1.weight.data, blk.norm1.bias.data, blk.norm1.eps, out=a["xn1"],
                             mean=a["m1"], rstd=a["r1"])
-            K.fused_attention_fwd(a["xn1"], self.Pk(blk.attn.qkv.weight), self.H, self.pe, out=a["a"])
+            if self.attn_fused:
+                K.fused_attention_fwd(a["xn1"], self.Pk(blk.attn.qkv.weight), self.H, self.pe, out=a["a"])
+            else:
+                K.linear(a["xn1"].view(M, D), self.Sh(blk.attn.qkv.weight), None, out=self.qkv_l[l].view(M, 3 * D))
+                K.attention_core_fwd(self.qkv_l[l], self.H, self.pe, out=a["a"])
             K.linear(a["a"].view(M, D), self.Sh(blk.attn.proj.weight), blk.attn.proj.bias.data, epi=L.EPI_BIAS_RESID,
                      resid=xin.view(M, D), out=a["xmid"].view(M, D))
             K.layernorm_fwd(a["xmid"], blk.norm2.weight.data, blk.norm2.bias.data, blk.norm2.eps, out=a["xn2"],
@@ -392,8 +403,11 @@ class TrainEngine:
             self._wgrad(e_dm, lambda: K.gemm_tn(dm, a["a"].view(M, D), G(blk.attn.proj.weight), G(blk.attn.proj.bias)))
             if not tail_done:
                 K.linear(dm, self.St(blk.attn.proj.weight), None, out=self.dtmp.view(M, D))
-            K.fused_attention_bwd(a["xn1"], self.Pk(blk.attn.qkv.weight), self.dtmp, self.H, self.pe,
-                                  out=dqkv, **self.pe_grads)
+            if self.attn_fused:
+                K.fused_attention_bwd(a["xn1"], self.Pk(blk.attn.qkv.weight), self.dtmp, self.H, self.pe,
+                                      out=dqkv, **self.pe_grads)
+            else:
+                K.attention_core_bwd(self.qkv_l[l], self.dtmp, self.H, self.pe, out=dqkv, **self.pe_grads)
             e_dq = ev()
             self._wgrad(e_dq, lambda: K.gemm_tn(dqkv.view(M, 3 * D), a["xn1"].view(M, D), G(blk.attn.qkv.weight), None))
             if self.fuse_ln_bwd:   # data gradient of qkv + LayerNorm1 backward + residual add in one kernel
