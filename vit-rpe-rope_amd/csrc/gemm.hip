@@ -802,6 +802,11 @@ extern "C" int vitpe_linear(int dtype, int epi, const void* A, const void* W, vo
     VITPE_REQUIRE(mean_out == nullptr);
     return vitpe_gemm_nt(dtype, epi, A, W, C, bias, R, U, nullptr, nullptr, M, N, K, 0, 0, stream);
   }
+  // The panel kernel wants M >> 256 x 144 rows: with fewer rows its panels are mostly padding and every one of
+  // them re-reads the whole weight (ViT-B/16 at batch 64: M = 12 608 -> 50-row panels, 240-300 TFLOP/s), while the
+  // 2-D tiled kernel runs the same shapes at 380-510 TFLOP/s (tools/kbench_imnet.py).  Big weights, few rows:
+  if (mean_out == nullptr && panel_rows_for(M, 144, 256) < 112 && N >= 384 && K >= 384)
+    return vitpe_gemm_nt(dtype, epi, A, W, C, bias, R, U, nullptr, nullptr, M, N, K, 0, 0, stream);
   GemmPanelArgs a{};
   a.A = A; a.W = W; a.C = C; a.bias = bias; a.R = R; a.U = U; a.mean_out = mean_out; a.rstd_out = rstd_out;
   a.M = M; a.N = N; a.K = K; a.eps = eps;
