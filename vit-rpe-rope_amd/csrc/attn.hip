@@ -404,9 +404,7 @@ __global__ __launch_bounds__(384) void attn_bwd_kernel(AttnArgs a) {
           const bool valid = qvalid && ((jt < MT - 1) || (j < N));
           const float ds = valid ? s[jt][r] * (dp[jt][r] - dl) : 0.f;
           dp[jt][r] = ds;
-          if (KM == KM_RELATIVE) {
-            if (valid) atomicAdd(&s_dtab[h * C::TABLD + (i - j + N - 1)], ds);
-          } else if (KM == KM_POLY) {
+          if (KM == KM_POLY) {
             if (valid && i >= 1 && j >= 1) {
               const int pi = i - 1, pj = j - 1, G = a.grid;
               const float x = (float)(abs(pi % G - pj % G) + abs(pi / G - pj / G));
@@ -419,6 +417,18 @@ __global__ __launch_bounds__(384) void attn_bwd_kernel(AttnArgs a) {
             }
           }
         }
+      if (KM == KM_RELATIVE) {   // dtab[i - j + N - 1] += dS[i][j] (invalid entries are zero), one diagonal per lane
+#pragma unroll
+        for (int jt = 0; jt < MT; ++jt) {
+          float d0, d1;
+          tile_diag_sums(dp[jt], lane, d0, d1);
+          const int idx0 = 16 * (it - jt) + c + N - 1;   // column - row == c ; d1: c - 16
+          if (g == 0) {
+            if (idx0 >= 0 && idx0 <= 2 * N - 2) atomicAdd(&s_dtab[h * C::TABLD + idx0], d0);
+            if (c >= 1 && idx0 - 16 >= 0 && idx0 - 16 <= 2 * N - 2) atomicAdd(&s_dtab[h * C::TABLD + idx0 - 16], d1);
+          }
+        }
+      }
       if (KM == KM_POLY) {
 #pragma unroll
         for (int k = 0; k <= C::MAXDEG; ++k) {

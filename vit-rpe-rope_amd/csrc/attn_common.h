@@ -89,6 +89,26 @@ VITPE_DEV float xg_sum(float v) {
   return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
+// Diagonal sums of a 16x16 tile in the C layout (lane (c,g), register r <-> row 4g+r, column c): every lane of
+// column c receives d0 = sum of the entries with column - row == c and d1 = sum of those with column - row == c - 16.
+// Used by the relative-position table gradient, dtab[i - j + N - 1] += dS[i][j]: reducing a tile's diagonals in
+// registers first (row q is rotated left by q, then the four lane groups are summed) turns 256 conflicting LDS
+// atomics per tile into 31 conflict-free ones.  Uniform control flow required (cross-lane reads).
+VITPE_DEV void tile_diag_sums(const f32x4& t, int lane, float& d0, float& d1) {
+  const int c = lane & 15, g = lane >> 4;
+  d0 = 0.f;
+  d1 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int rot = 4 * g + r;
+    const float v = __shfl(t[r], (lane & 48) | ((c + rot) & 15), 64);   // entry (row rot, column (c + rot) & 15)
+    if (c + rot >= 16) d1 += v;
+    else d0 += v;
+  }
+  d0 = xg_sum(d0);
+  d1 = xg_sum(d1);
+}
+
 // additive logit bias (already multiplied by log2 e when staged) for (query i, key j) of head h
 template <typename C, int KM>
 VITPE_DEV float pe_bias2(const AttnArgs& a, const float* s_tab, const float* s_coef, int h, int i, int j, int N) {
