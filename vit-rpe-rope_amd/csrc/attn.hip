@@ -83,14 +83,7 @@ VITPE_DEV void stage_tokens(const AttnArgs& a, int b, T* xs, T* hbuf, int hbuf_e
       s_tab[q] = (i < 2 * N - 1) ? a.table[h * (2 * N - 1) + i] * LOG2E : 0.f;
     }
   }
-  if (KM == KM_POLY && stage_tables) {
-    for (int q = tid; q < C::H * (C::MAXDEG + 1); q += nthreads) {
-      const int h = q / (C::MAXDEG + 1), k = q % (C::MAXDEG + 1);
-      float v = 0.f;
-      if (k <= a.degree) v = a.coeff_per_head ? a.coeff[h * (a.degree + 1) + k] : a.coeff[k];
-      s_coef[q] = v * LOG2E;
-    }
-  }
+  if (KM == KM_POLY && stage_tables) stage_poly<C>(a, 0, s_coef, N, tid, nthreads);
 }
 
 // ---- QKV projection of one (head, matrix) by one wave, RoPE + scale, result to LDS --------
@@ -192,7 +185,7 @@ __global__ __launch_bounds__(384 * IPW) void attn_fwd_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) T xs_all[IPW * C::NP * C::LDX];
   __shared__ __attribute__((aligned(16))) T hb_all[IPW * HB_ELEMS];
   __shared__ __attribute__((aligned(16))) float s_tab[KM == KM_RELATIVE ? C::H * C::TABLD : 4];
-  __shared__ float s_coef[C::H * (C::MAXDEG + 1)];
+  __shared__ __attribute__((aligned(16))) float s_coef[KM == KM_POLY ? C::PESZ : 4];
 
   const int N = C::ntok(a);
   const int lane = threadIdx.x & 63;
@@ -293,7 +286,7 @@ __global__ __launch_bounds__(384) void attn_bwd_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) T xs[C::NP * C::LDX];
   __shared__ __attribute__((aligned(16))) T hb[4 * HPP * C::HSZ];  // q,k,v,dO: [mat][hh][VR][LDH]
   __shared__ __attribute__((aligned(16))) float s_tab[KM == KM_RELATIVE ? C::H * C::TABLD : 4];
-  __shared__ float s_coef[C::H * (C::MAXDEG + 1)];
+  __shared__ __attribute__((aligned(16))) float s_coef[KM == KM_POLY ? C::PESZ : 4];
   __shared__ __attribute__((aligned(16))) float s_stat[HPP * 2 * C::NP];  // [hh][lse2 | delta][token]
   __shared__ float s_dtab[KM == KM_RELATIVE ? C::H * C::TABLD : 4];  // relative-table gradient of this image
   __shared__ float s_dcoef[C::H * (C::MAXDEG + 1)];
@@ -406,8 +399,7 @@ __global__ __launch_bounds__(384) void attn_bwd_kernel(AttnArgs a) {
           dp[jt][r] = ds;
           if (KM == KM_POLY) {
             if (valid && i >= 1 && j >= 1) {
-              const int pi = i - 1, pj = j - 1, G = a.grid;
-              const float x = (float)(abs(pi % G - pj % G) + abs(pi / G - pj / G));
+              const float x = (float)pe_l1<C>(s_coef, i, j);
               float pw = 1.f;
 #pragma unroll
               for (int k = 0; k <= C::MAXDEG; ++k) {

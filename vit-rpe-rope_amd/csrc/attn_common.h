@@ -70,6 +70,8 @@ struct AttnCfg {
   static constexpr int QSZ = NP * LDH;            // same without the tail (row-read operands only)
   static constexpr int TABLD = 2 * NP;
   static constexpr int MAXDEG = 7;
+  static constexpr int PBLD = 32;                 // polynomial bias by L1 grid distance: entries per head (grid <= 16)
+  static constexpr int PESZ = H * PBLD + NP;      // s_coef: [H][PBLD] bias-by-distance (x log2 e), then NP packed (x | y << 8) token coordinates
   static constexpr int DD = D, HDD = HD, MTT = MT;
   static_assert(HD % 32 == 0 && D % HD == 0 && D % 32 == 0, "shape");
   static __device__ __forceinline__ int ntok(const AttnArgs& a) { return NTOK ? NTOK : a.N; }
@@ -109,6 +111,31 @@ VITPE_DEV void tile_diag_sums(const f32x4& t, int lane, float& d0, float& d1) {
   d1 = xg_sum(d1);
 }
 
+// L1 grid distance of patch tokens i, j >= 1 (positional_encoding.py:136-142) from the packed coordinates staged behind
+// the bias table
+template <typename C>
+VITPE_DEV int pe_l1(const float* s_coef, int i, int j) {
+  const int* xy = reinterpret_cast<const int*>(s_coef + C::H * C::PBLD);
+  return (int)__builtin_amdgcn_sad_u8((unsigned)xy[i], (unsigned)xy[j], 0u);
+}
+// fill s_coef for KM_POLY: bias-by-distance table of heads [hbase, hbase + C::H) and the token coordinates
+template <typename C>
+VITPE_DEV void stage_poly(const AttnArgs& a, int hbase, float* s_coef, int N, int tid, int nthreads) {
+  for (int q = tid; q < C::H * C::PBLD; q += nthreads) {
+    const int h = q / C::PBLD, l = q % C::PBLD;
+    const float* cf = a.coeff + (a.coeff_per_head ? (hbase + h) * (a.degree + 1) : 0);
+    const float x = (float)l;
+    float v = cf[a.degree];
+    for (int k = a.degree - 1; k >= 0; --k) v = v * x + cf[k];
+    s_coef[q] = v * LOG2E;
+  }
+  int* xy = reinterpret_cast<int*>(s_coef + C::H * C::PBLD);
+  for (int t = tid; t < C::NP; t += nthreads) {
+    const int pi = t - 1;
+    xy[t] = (t >= 1 && t < N) ? ((pi % a.grid) | ((pi / a.grid) << 8)) : 0;
+  }
+}
+
 // additive logit bias (already multiplied by log2 e when staged) for (query i, key j) of head h
 template <typename C, int KM>
 VITPE_DEV float pe_bias2(const AttnArgs& a, const float* s_tab, const float* s_coef, int h, int i, int j, int N) {
@@ -119,13 +146,9 @@ VITPE_DEV float pe_bias2(const AttnArgs& a, const float* s_tab, const float* s_c
   }
   if (KM == KM_POLY) {
     if (i < 1 || j < 1) return 0.f;  // class row / column stay zero (positional_encoding.py:165-169)
-    const int pi = i - 1, pj = j - 1, G = a.grid;
-    const int l1 = abs(pi % G - pj % G) + abs(pi / G - pj / G);
-    const float* cf = s_coef + (a.coeff_per_head ? h * (C::MAXDEG + 1) : 0);
-    const float x = (float)l1;
-    float v = cf[a.degree];
-    for (int k = a.degree - 1; k >= 0; --k) v = v * x + cf[k];
-    return v;
+    // polynomial of the L1 grid distance: tabulated per head and distance when the kernel starts (the distance is
+    // one v_sad_u8 on packed coordinates -- the per-element integer div/mod and Horner chain were the cost of this mode)
+    return s_coef[(a.coeff_per_head ? h : 0) * C::PBLD + pe_l1<C>(s_coef, i, j)];
   }
   return 0.f;
 }

@@ -87,12 +87,7 @@ VITPE_DEV void stage_pe(const AttnArgs& a, int hg, float* s_tab, float* s_coef, 
   if (KM == KM_RELATIVE)
     for (int i = tid; i < C::TABLD; i += nthreads)
       s_tab[i] = (i < 2 * N - 1) ? a.table[(size_t)hg * (2 * N - 1) + i] * LOG2E : 0.f;
-  if (KM == KM_POLY)
-    for (int k = tid; k <= C::MAXDEG; k += nthreads) {
-      float v = 0.f;
-      if (k <= a.degree) v = a.coeff_per_head ? a.coeff[hg * (a.degree + 1) + k] : a.coeff[k];
-      s_coef[k] = v * LOG2E;
-    }
+  if (KM == KM_POLY) stage_poly<C>(a, hg, s_coef, N, tid, nthreads);
 }
 
 // =========================================================================================
@@ -105,7 +100,7 @@ __global__ __launch_bounds__(64 * NW) void attn_core_fwd_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) T kt[C::QSZ];  // K~ (row reads only)
   __shared__ __attribute__((aligned(16))) T vt[C::HSZ];  // V (column reads run into the zero tail)
   __shared__ __attribute__((aligned(16))) float s_tab[KM == KM_RELATIVE ? C::TABLD : 4];
-  __shared__ float s_coef[C::MAXDEG + 1];
+  __shared__ __attribute__((aligned(16))) float s_coef[KM == KM_POLY ? C::PESZ : 4];
 
   const int N = a.N, H = a.H, Dr = H * HD, P = N - 1;
   const int b = blockIdx.x / H, hg = blockIdx.x % H;
@@ -175,7 +170,7 @@ __global__ __launch_bounds__(64 * NW) void attn_core_bwd_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) T t0[C::HSZ];  // step 1: K~ ; step 2: q~
   __shared__ __attribute__((aligned(16))) T t1[C::HSZ];  // step 1: V  ; step 2: dO
   __shared__ __attribute__((aligned(16))) float s_tab[KM == KM_RELATIVE ? C::TABLD : 4];
-  __shared__ float s_coef[C::MAXDEG + 1];
+  __shared__ __attribute__((aligned(16))) float s_coef[KM == KM_POLY ? C::PESZ : 4];
   __shared__ __attribute__((aligned(16))) float s_stat[2 * C::NP];  // [lse2 | delta][token]
   __shared__ float s_dtab[KM == KM_RELATIVE ? C::TABLD : 4];
   __shared__ float s_dcoef[C::MAXDEG + 1];
@@ -268,8 +263,7 @@ __global__ __launch_bounds__(64 * NW) void attn_core_bwd_kernel(AttnArgs a) {
         dp[jt][r] = ds;
         if (KM == KM_POLY) {
           if (valid && i >= 1 && j >= 1) {
-            const int pi = i - 1, pj = j - 1, G = a.grid;
-            const float x = (float)(abs(pi % G - pj % G) + abs(pi / G - pj / G));
+            const float x = (float)pe_l1<C>(s_coef, i, j);
             float pw = 1.f;
 #pragma unroll
             for (int k = 0; k <= C::MAXDEG; ++k) {
