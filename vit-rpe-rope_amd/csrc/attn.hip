@@ -442,6 +442,21 @@ __global__ __launch_bounds__(384) void attn_bwd_kernel(AttnArgs a) {
           mma(ld_frag_tr(kh, C::LDH, 32 * sc + 4 * g, 32 * sc + 16 + 4 * g, 16 * dt), bs, dqa[dt]);
       }
       // inverse rotation (+ RoPE-mixed phase gradient), undo the folded scale, store the q part
+      if (mixed) {   // (uniform branch: the row reductions inside need every lane)
+        // dL/dphase = (dq~2 q~1 - dq~1 q~2) with q~ = scale*log2e*rot(q) held in LDS and
+        // dqa = dL/d(rot q)/scale: the scale cancels, log2e does not -> ln2
+        const bool tok_ok = i >= 1 && i < N;
+        const int il = min(i, C::NP - 1);
+#pragma unroll
+        for (int nt = 0; nt < C::NT / 2; ++nt) {
+          const f32x4 q1 = ld4(qh + il * C::LDH + 16 * nt + 4 * g);
+          const f32x4 q2 = ld4(qh + il * C::LDH + 16 * (nt + C::NT / 2) + 4 * g);
+          f32x4 dph;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dph[r] = dqa[nt + C::NT / 2][r] * q1[r] - dqa[nt][r] * q2[r];
+          mixed_freq_grad_tile(s_dfreq, dph, i, tok_ok, 16 * it, h, C::H, P, a.grid, HD / 2, 16 * nt + 4 * g, LN2, lane);
+        }
+      }
       if (KM == KM_ROPE && i >= 1 && i < N) {
         const size_t hoff = mixed ? (size_t)h * P * (HD / 2) : 0;
 #pragma unroll
@@ -449,21 +464,6 @@ __global__ __launch_bounds__(384) void attn_bwd_kernel(AttnArgs a) {
           const size_t o = hoff + (size_t)(i - 1) * (HD / 2) + 16 * nt + 4 * g;
           const f32x4 cs = *reinterpret_cast<const f32x4*>(a.cos + o);
           const f32x4 sn = *reinterpret_cast<const f32x4*>(a.sin + o);
-          if (mixed) {
-            // dL/dphase = (dq~2 q~1 - dq~1 q~2) with q~ = scale*log2e*rot(q) held in LDS and
-            // dqa = dL/d(rot q)/scale: the scale cancels, log2e does not -> ln2
-            const f32x4 q1 = ld4(qh + i * C::LDH + 16 * nt + 4 * g);
-            const f32x4 q2 = ld4(qh + i * C::LDH + 16 * (nt + C::NT / 2) + 4 * g);
-            const int flat = (i - 1) * C::H + h;  // view-scramble: slot [h, i-1] holds head flat/P at pos flat%P
-            const int hs = flat / P, ps = flat % P;
-            const float tx = (float)(ps % a.grid) * LN2, ty = (float)(ps / a.grid) * LN2;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float dph = dqa[nt + C::NT / 2][r] * q1[r] - dqa[nt][r] * q2[r];
-              atomicAdd(&s_dfreq[(0 * C::H + hs) * (HD / 2) + 16 * nt + 4 * g + r], tx * dph);
-              atomicAdd(&s_dfreq[(1 * C::H + hs) * (HD / 2) + 16 * nt + 4 * g + r], ty * dph);
-            }
-          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float d1 = dqa[nt][r], d2 = dqa[nt + C::NT / 2][r];
@@ -539,6 +539,19 @@ __global__ __launch_bounds__(384) void attn_bwd_kernel(AttnArgs a) {
       for (int dt = 0; dt < C::NT; ++dt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dka[dt][r] *= LN2;
+      if (mixed) {   // (uniform branch; see step 1)
+        const bool tok_ok = j >= 1 && j < N;
+        const int jl = min(j, C::NP - 1);
+#pragma unroll
+        for (int nt = 0; nt < C::NT / 2; ++nt) {
+          const f32x4 k1 = ld4(kh + jl * C::LDH + 16 * nt + 4 * g);
+          const f32x4 k2 = ld4(kh + jl * C::LDH + 16 * (nt + C::NT / 2) + 4 * g);
+          f32x4 dph;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dph[r] = dka[nt + C::NT / 2][r] * k1[r] - dka[nt][r] * k2[r];
+          mixed_freq_grad_tile(s_dfreq, dph, j, tok_ok, 16 * jt, h, C::H, P, a.grid, HD / 2, 16 * nt + 4 * g, 1.0f, lane);
+        }
+      }
       if (KM == KM_ROPE && j >= 1 && j < N) {
         const size_t hoff = mixed ? (size_t)h * P * (HD / 2) : 0;
 #pragma unroll
@@ -546,19 +559,6 @@ __global__ __launch_bounds__(384) void attn_bwd_kernel(AttnArgs a) {
           const size_t o = hoff + (size_t)(j - 1) * (HD / 2) + 16 * nt + 4 * g;
           const f32x4 cs = *reinterpret_cast<const f32x4*>(a.cos + o);
           const f32x4 sn = *reinterpret_cast<const f32x4*>(a.sin + o);
-          if (mixed) {
-            const f32x4 k1 = ld4(kh + j * C::LDH + 16 * nt + 4 * g);
-            const f32x4 k2 = ld4(kh + j * C::LDH + 16 * (nt + C::NT / 2) + 4 * g);
-            const int flat = (j - 1) * C::H + h;
-            const int hs = flat / P, ps = flat % P;
-            const float tx = (float)(ps % a.grid), ty = (float)(ps / a.grid);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float dph = dka[nt + C::NT / 2][r] * k1[r] - dka[nt][r] * k2[r];
-              atomicAdd(&s_dfreq[(0 * C::H + hs) * (HD / 2) + 16 * nt + 4 * g + r], tx * dph);
-              atomicAdd(&s_dfreq[(1 * C::H + hs) * (HD / 2) + 16 * nt + 4 * g + r], ty * dph);
-            }
-          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float d1 = dka[nt][r], d2 = dka[nt + C::NT / 2][r];

@@ -111,6 +111,45 @@ VITPE_DEV void tile_diag_sums(const f32x4& t, int lane, float& d0, float& d1) {
   d1 = xg_sum(d1);
 }
 
+// Sum over the 16 lanes of a row (lanes 16g .. 16g+15), valid in lane 15 of the row: four DPP row_shr adds on the
+// VALU (no LDS traffic).  Uniform control flow required.
+VITPE_DEV float row16_sum_lane15(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true));  // row_shr:1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xF, 0xF, true));  // row_shr:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xF, 0xF, true));  // row_shr:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xF, 0xF, true));  // row_shr:8
+  return v;
+}
+
+// RoPE-mixed frequency gradient of one 16-token tile (positional_encoding.py:313-351 through the view-scramble):
+// lane (c, g) holds, for token tok = tok0 + c and features f0 + r (r < 4), the phase gradient dph[r]; the token's
+// rotation slot [h, tok-1] carries head hs = flat / P at grid position ps = flat % P, flat = (tok-1)*H + h, so
+//   dfreq[0][hs][f] += (ps % grid) * dph ,  dfreq[1][hs][f] += (ps / grid) * dph   (x scale).
+// The 16 tokens of a tile map to at most (15*H)/P + 2 consecutive hs values: for each candidate the row is reduced
+// with DPP adds and ONE lane per row issues the LDS atomic (the per-lane atomics were 16-way same-address conflicts).
+VITPE_DEV void mixed_freq_grad_tile(float* s_dfreq, const f32x4& dph, int tok, bool tok_ok, int tok0, int h, int H, int P,
+                                    int grid, int half, int f0, float scale, int lane) {
+  const int c = lane & 15;
+  const int flat = (max(tok, 1) - 1) * H + h;
+  const int hs = flat / P, ps = flat - hs * P;
+  const float tx = tok_ok ? (float)(ps % grid) * scale : 0.f, ty = tok_ok ? (float)(ps / grid) * scale : 0.f;
+  const int hs_first = ((max(tok0, 1) - 1) * H + h) / P;     // wave-uniform
+  const int ncand = (15 * H) / P + 2;
+  for (int k = 0; k < ncand; ++k) {
+    const int hsv = hs_first + k;
+    if (hsv >= H) break;
+    const float mx = (hs == hsv) ? tx : 0.f, my = (hs == hsv) ? ty : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float sx = row16_sum_lane15(mx * dph[r]), sy = row16_sum_lane15(my * dph[r]);
+      if (c == 15) {
+        atomicAdd(&s_dfreq[(0 * H + hsv) * half + f0 + r], sx);
+        atomicAdd(&s_dfreq[(1 * H + hsv) * half + f0 + r], sy);
+      }
+    }
+  }
+}
+
 // L1 grid distance of patch tokens i, j >= 1 (positional_encoding.py:136-142) from the packed coordinates staged behind
 // the bias table
 template <typename C>
