@@ -306,26 +306,29 @@ __global__ __launch_bounds__(64 * NW) void attn_core_bwd_kernel(AttnArgs a) {
         mma(ld_frag_tr(kh, C::LDH, 32 * sc + 4 * g, 32 * sc + 16 + 4 * g, 16 * dt), bs, dqa[dt]);
       if (MT > 8) __builtin_amdgcn_sched_barrier(0);
     }
+    if (mixed) {   // uniform branch: row reductions inside (mixed_freq_grad_tile, attn_common.h)
+      // dL/dphase = (dq~2 q~1 - dq~1 q~2), q~ = scale*log2e*rot(q) (see attn.hip): ln2 undoes the log2e
+      const bool tok_ok = i >= 1 && i < N;
+#pragma unroll
+      for (int nt = 0; nt < C::NT / 2; ++nt) {
+        const f32x4 cs = *reinterpret_cast<const f32x4*>(csr + 16 * nt + 4 * g);
+        const f32x4 sn = *reinterpret_cast<const f32x4*>(snr + 16 * nt + 4 * g);
+        const f32x4 x1 = ld4(qg + (size_t)il * 3 * Dr + 16 * nt + 4 * g);
+        const f32x4 x2 = ld4(qg + (size_t)il * 3 * Dr + 16 * (nt + C::NT / 2) + 4 * g);
+        f32x4 dph;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float q1 = (x1[r] * cs[r] - x2[r] * sn[r]) * qsc, q2 = (x1[r] * sn[r] + x2[r] * cs[r]) * qsc;
+          dph[r] = dqa[nt + C::NT / 2][r] * q1 - dqa[nt][r] * q2;
+        }
+        mixed_freq_grad_tile(s_dfreq, dph, i, tok_ok, 16 * it, hg, H, P, a.grid, HD / 2, 16 * nt + 4 * g, LN2, lane);
+      }
+    }
     if (ROPE && i >= 1 && i < N) {
 #pragma unroll
       for (int nt = 0; nt < C::NT / 2; ++nt) {
         const f32x4 cs = *reinterpret_cast<const f32x4*>(csr + 16 * nt + 4 * g);
         const f32x4 sn = *reinterpret_cast<const f32x4*>(snr + 16 * nt + 4 * g);
-        if (mixed) {
-          // dL/dphase = (dq~2 q~1 - dq~1 q~2), q~ = scale*log2e*rot(q) (see attn.hip): ln2 undoes the log2e
-          const f32x4 x1 = ld4(qg + (size_t)i * 3 * Dr + 16 * nt + 4 * g);
-          const f32x4 x2 = ld4(qg + (size_t)i * 3 * Dr + 16 * (nt + C::NT / 2) + 4 * g);
-          const int flat = (i - 1) * H + hg;  // view-scramble: slot [h, i-1] holds head flat/P at pos flat%P
-          const int hs = flat / P, ps = flat % P;
-          const float tx = (float)(ps % a.grid) * LN2, ty = (float)(ps / a.grid) * LN2;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float q1 = (x1[r] * cs[r] - x2[r] * sn[r]) * qsc, q2 = (x1[r] * sn[r] + x2[r] * cs[r]) * qsc;
-            const float dph = dqa[nt + C::NT / 2][r] * q1 - dqa[nt][r] * q2;
-            atomicAdd(&s_dfreq[(0 * H + hs) * (HD / 2) + 16 * nt + 4 * g + r], tx * dph);
-            atomicAdd(&s_dfreq[(1 * H + hs) * (HD / 2) + 16 * nt + 4 * g + r], ty * dph);
-          }
-        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float d1 = dqa[nt][r], d2 = dqa[nt + C::NT / 2][r];
@@ -410,25 +413,28 @@ __global__ __launch_bounds__(64 * NW) void attn_core_bwd_kernel(AttnArgs a) {
     for (int dt = 0; dt < C::NT; ++dt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) dka[dt][r] *= LN2;
+    if (mixed) {
+      const bool tok_ok = j >= 1 && j < N;
+#pragma unroll
+      for (int nt = 0; nt < C::NT / 2; ++nt) {
+        const f32x4 cs = *reinterpret_cast<const f32x4*>(csr + 16 * nt + 4 * g);
+        const f32x4 sn = *reinterpret_cast<const f32x4*>(snr + 16 * nt + 4 * g);
+        const f32x4 x1 = ld4(qg + Dr + (size_t)jl * 3 * Dr + 16 * nt + 4 * g);
+        const f32x4 x2 = ld4(qg + Dr + (size_t)jl * 3 * Dr + 16 * (nt + C::NT / 2) + 4 * g);
+        f32x4 dph;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float k1 = x1[r] * cs[r] - x2[r] * sn[r], k2 = x1[r] * sn[r] + x2[r] * cs[r];
+          dph[r] = dka[nt + C::NT / 2][r] * k1 - dka[nt][r] * k2;
+        }
+        mixed_freq_grad_tile(s_dfreq, dph, j, tok_ok, 16 * jt, hg, H, P, a.grid, HD / 2, 16 * nt + 4 * g, 1.0f, lane);
+      }
+    }
     if (ROPE && j >= 1 && j < N) {
 #pragma unroll
       for (int nt = 0; nt < C::NT / 2; ++nt) {
         const f32x4 cs = *reinterpret_cast<const f32x4*>(csr + 16 * nt + 4 * g);
         const f32x4 sn = *reinterpret_cast<const f32x4*>(snr + 16 * nt + 4 * g);
-        if (mixed) {
-          const f32x4 x1 = ld4(qg + Dr + (size_t)j * 3 * Dr + 16 * nt + 4 * g);
-          const f32x4 x2 = ld4(qg + Dr + (size_t)j * 3 * Dr + 16 * (nt + C::NT / 2) + 4 * g);
-          const int flat = (j - 1) * H + hg;
-          const int hs = flat / P, ps = flat % P;
-          const float tx = (float)(ps % a.grid), ty = (float)(ps / a.grid);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float k1 = x1[r] * cs[r] - x2[r] * sn[r], k2 = x1[r] * sn[r] + x2[r] * cs[r];
-            const float dph = dka[nt + C::NT / 2][r] * k1 - dka[nt][r] * k2;
-            atomicAdd(&s_dfreq[(0 * H + hs) * (HD / 2) + 16 * nt + 4 * g + r], tx * dph);
-            atomicAdd(&s_dfreq[(1 * H + hs) * (HD / 2) + 16 * nt + 4 * g + r], ty * dph);
-          }
-        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float d1 = dka[nt][r], d2 = dka[nt + C::NT / 2][r];
