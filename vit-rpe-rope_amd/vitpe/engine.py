@@ -15,6 +15,7 @@
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -46,15 +47,15 @@ class TrainEngine:
         # = forward and backward (default), "fwd" = forward only (stand-alone LayerNorm-backward kernel),
         # False = stand-alone LayerNorm kernels everywhere.
         ok = m.embed_dim == 192
-        if fuse_ln is None and "VITPE_FUSE_LN" in __import__("os").environ:   # experiment switch: fwd | all | off
-            fuse_ln = {"fwd": "fwd", "all": True, "off": False}[__import__("os").environ["VITPE_FUSE_LN"]]
+        if fuse_ln is None and "VITPE_FUSE_LN" in os.environ:   # experiment switch: fwd | all | off
+            fuse_ln = {"fwd": "fwd", "all": True, "off": False}[os.environ["VITPE_FUSE_LN"]]
         self.fuse_ln = ok and fuse_ln is not False
         self.fuse_ln_bwd = ok and (fuse_ln is True or fuse_ln is None)
         # whole-MLP-branch forward kernel (bf16, d = 192 only; VITPE_FUSE_MLP=0 falls back to two panel GEMMs)
         self.fuse_mlp = (self.fuse_ln and compute_dtype == torch.bfloat16
-                         and __import__("os").environ.get("VITPE_FUSE_MLP", "1") == "1"
+                         and os.environ.get("VITPE_FUSE_MLP", "1") == "1"
                          and K.mlp_fwd_supported(compute_dtype, m.embed_dim, m.blocks[0].mlp.fc1.out_features))
-        self.fuse_tail = __import__("os").environ.get("VITPE_FUSE_TAIL", "1") == "1"   # proj folded into the MLP kernel
+        self.fuse_tail = os.environ.get("VITPE_FUSE_TAIL", "1") == "1"   # proj folded into the MLP kernel
         self.D, self.H, self.Lyr = m.embed_dim, m.num_heads, len(m.blocks)
         self.p = m.patch_size
         self.C = m.patch_embed.weight.shape[1]
@@ -187,7 +188,7 @@ class TrainEngine:
         self.head_scratch = torch.zeros(4, dtype=torch.float32, device=dev)
         # one-launch head + CE + head backward (vitpe_head_loss): measured 45 us against 40 us for the three small
         # kernels it replaces (one wave per image is a long serial chain) -- off unless VITPE_FUSE_HEAD=1
-        self.fuse_head = self.Cn <= 64 and __import__("os").environ.get("VITPE_FUSE_HEAD", "0") == "1"
+        self.fuse_head = self.Cn <= 64 and os.environ.get("VITPE_FUSE_HEAD", "0") == "1"
         self.head_ws = (f(B, D), f(B, D), f(B))
         self.ws_dyn = f(B, D)
         # Gradient tensors read by the weight-gradient GEMMs get per-layer buffers (dy = d x_out, dmid = d x_mid,
@@ -202,9 +203,9 @@ class TrainEngine:
         self.dqkv, self.du = self.dqkv_l[0], self.du_l[0]          # (bench.py times the kernels on these)
         self.side = torch.cuda.Stream(device=dev)
         self.dataset, self.batch_idx = None, None
-        self.overlap_wgrad = __import__("os").environ.get("VITPE_OVERLAP_WGRAD", "0") == "1"
+        self.overlap_wgrad = os.environ.get("VITPE_OVERLAP_WGRAD", "0") == "1"
         # weight gradients: one grouped launch per backward part (default) or one GEMM per nn.Linear
-        self.group_wgrad = __import__("os").environ.get("VITPE_GROUP_WGRAD", "1") == "1" and not self.overlap_wgrad
+        self.group_wgrad = os.environ.get("VITPE_GROUP_WGRAD", "1") == "1" and not self.overlap_wgrad
         self._wg_groups = {}
         self.dpatch = e(B * self.P, D)
         self.ln_ws = K.layernorm_bwd_workspace(M, D, dev)

@@ -7,6 +7,7 @@ in Python; there is no fallback path.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -14,7 +15,7 @@ import torch
 from . import _lib as L
 from ._lib import check, dtype_code, lib, ptr, require_device, stream_ptr
 
-SPLITS_TARGET_WGS = int(__import__("os").environ.get("VITPE_WGRAD_WGS", "512"))  # workgroups a weight-gradient launch should expose
+SPLITS_TARGET_WGS = int(os.environ.get("VITPE_WGRAD_WGS", "512"))  # workgroups a weight-gradient launch should expose
 
 
 def _f32(t, name):
