@@ -412,3 +412,15 @@ def test_engine_imagenet_geometry_bf16_learns():
         eng.step(images, labels)
         losses.append(eng.read_metrics()[0])
     assert losses[-1] < 0.5 * losses[0], losses
+
+
+def test_train_py_synthetic_mode_runs(tmp_path):
+    """train.py --synthetic (the offline stand-in for the reference's dataset download): one short epoch per mode
+    family, CSV + checkpoint written with the reference's naming."""
+    import train as T
+    for mode in ("absolute", "polynomial"):
+        T.main(["--dataset", "mnist", "--pos_encoding", mode, "--batch_size", "16", "--epochs", "1", "--synthetic",
+                "--steps_per_epoch", "3", "--embed_dim", "96", "--depth", "2", "--num_heads", "3",
+                "--log_dir", str(tmp_path / "logs"), "--ckpt_dir", str(tmp_path / "ckpt")])
+        assert (tmp_path / "ckpt" / f"mnist_{mode}_best.pth").exists()
+        assert len(list((tmp_path / "logs").glob(f"mnist_{mode}_*.csv"))) == 1
