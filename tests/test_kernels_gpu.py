@@ -359,6 +359,30 @@ def test_wgrad_group_large_balanced_run(K):
         assert rel_err(db.cpu(), rb) < 1e-4
 
 
+@pytest.mark.parametrize("M", [65 * 64, 65 * 64 + 7])
+def test_wgrad_group_whole_model_list(K, M):
+    """A whole-model problem list (6 x {fc2, fc1, proj, qkv} + patch embed), the shape of the engine's launch: big
+    enough for the XCD-co-located (block, token-range) table; ragged last stage when M % 64 != 0."""
+    D, hid = 192, 768
+    probs, refs = [], []
+    shapes = [(D, hid, True), (hid, D, True), (D, D, True), (3 * D, D, False)] * 6 + [(D, 48, True)]
+    for i, (N, K_, bias) in enumerate(shapes):
+        dy, x = rnd(M, N, seed=200 + i), rnd(M, K_, seed=300 + i)
+        dw = torch.zeros(N, K_, device="cuda")
+        db = torch.zeros(N, device="cuda") if bias else None
+        probs.append((dev(dy, torch.bfloat16), dev(x, torch.bfloat16), dw, db))
+        refs.append((q(dy, "bf16").t() @ q(x, "bf16"), q(dy, "bf16").sum(0)))
+    grp = K.WgradGroup(probs)
+    grp.launch()
+    for (dy, x, dw, db), (rw, rb) in zip(probs, refs):
+        assert rel_err(dw.cpu(), rw) < 1e-4, tuple(dw.shape)
+        if db is not None:
+            assert rel_err(db.cpu(), rb) < 1e-4, tuple(dw.shape)
+    grp.launch()   # accumulates
+    for (dy, x, dw, db), (rw, rb) in zip(probs, refs):
+        assert rel_err(dw.cpu(), 2 * rw) < 1e-4
+
+
 def test_wgrad_group_rejects_bad_lists(K):
     from vitpe._lib import VitpeError
     with pytest.raises(VitpeError):
