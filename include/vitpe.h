@@ -238,6 +238,12 @@ int vitpe_head_fwd(int dtype, const void* x, const float* gamma, const float* be
 /* out2[0] = mean CE, out2[1] = #correct; dlogits (NULL to skip) = (softmax-onehot)*grad_scale */
 int vitpe_cross_entropy(const float* logits, const long long* labels, float* dlogits, float* out2,
                         int B, int Cn, float grad_scale, vitpe_stream_t stream);
+/* The same with its scalars read ON THE DEVICE (a captured step follows a ragged last batch; reference train.py:89-90
+ * has no drop_last): ctl = {grad_scale, loss_scale, n_valid}.  Rows b >= n_valid are padding: dlogits = 0 (so every
+ * gradient downstream is untouched by them), left out of loss and accuracy.  out2[0] = loss_scale * sum of the valid
+ * rows' losses, out2[1] = #correct; metric_acc (nullable) += out2.                                                  */
+int vitpe_cross_entropy_ctl(const float* logits, const long long* labels, float* dlogits, float* out2,
+                            float* metric_acc, const float* ctl, int B, int Cn, vitpe_stream_t stream);
 int vitpe_head_bwd(int dtype, const float* dlogits, const float* Wh, const float* gamma,
                    const float* ws_xhat, const float* ws_yn, const float* ws_rstd, float* ws_dyn,
                    void* dx, float* dWh, float* dbh, float* dgamma, float* dbeta, int B, int Ntok,

@@ -191,3 +191,65 @@ def test_oracle_input_transform_matches_its_definition():
         assert torch.equal(y[0, c], (v - mean[c]) / std[c])
     from vitpe import data as D
     assert D.DATASET_STATS == O.DATASET_STATS                     # train.py:72,81 constants on both sides
+
+
+def test_epoch_global_batches_keep_the_ragged_tail_on_every_rank():
+    """reference DataLoader(batch_size, drop_last=False) (train.py:89-90): every sample once per epoch, last batch
+    ragged (50000 % 128 = 80); all ranks make the same number of steps and the shares of a global batch are disjoint."""
+    from vitpe import data as D
+    n, G, world = 203, 32, 4
+    steps = None
+    seen, per_step_global = [], {}
+    for rank in range(world):
+        its = list(D.epoch_global_batches(n, G, 3, seed=7, shuffle=True, rank=rank, world=world, device="cpu"))
+        steps = steps or len(its)
+        assert len(its) == steps == (n + G - 1) // G
+        for k, (idx, n_local, n_global) in enumerate(its):
+            assert idx.dtype == torch.int64 and idx.numel() == max(n_local, 1) and 0 <= n_local <= G // world
+            assert per_step_global.setdefault(k, n_global) == n_global
+            seen += [int(i) for i in idx[:n_local]]
+    assert sorted(seen) == list(range(n))                                  # each sample exactly once
+    assert [per_step_global[k] for k in range(steps)] == [32] * 6 + [203 - 192]
+    # the tail batch of 11 falls entirely into the shares of ranks 0 (8) and 1 (3); ranks 2, 3 run an empty share
+    tails = [list(D.epoch_global_batches(n, G, 3, seed=7, rank=r, world=world, device="cpu"))[-1] for r in range(world)]
+    assert [t[1] for t in tails] == [8, 3, 0, 0]
+    order = [int(i) for idx, nl, _ in D.epoch_global_batches(10, 4, 0, shuffle=False, device="cpu") for i in idx[:nl]]
+    assert order == list(range(10))
+    with pytest.raises(ValueError):
+        next(D.epoch_global_batches(10, 6, 0, world=4, device="cpu"))
+
+
+def _run_bench(args, env_extra=None, launcher=False):
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    bench = os.path.join(REPO, "bench.py")
+    cmd = [sys.executable]
+    if launcher:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(29800 + os.getpid() % 150)]
+    r = subprocess.run(cmd + [bench] + args, env=env, capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r.returncode, [json.loads(ln) for ln in lines], r.stderr
+
+
+@pytest.mark.parametrize("launcher", [False, True])
+def test_bench_starts_its_own_ranks_and_also_runs_under_the_launcher(launcher):
+    """`python bench.py --gpus 2` (what the driver types) must start 2 ranks itself; under torch.distributed.run it is
+    the rank it is told to be.  --dry-run: CPU ranks over gloo, no GPU (the JSON contract and the rendezvous only)."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"], launcher=launcher)
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1                                   # rank 0 prints ONE line
+    ln = lines[0]
+    assert ln["n_gpus"] == 2 and ln["n_ranks_seen"] == 2 and ln["steps"] == 3 and ln["warmup"] == 1
+    assert ln["config"]["global_batch"] == 2 * ln["config"]["per_gpu_batch"] and ln["config"]["parallelism"] == "dp2"
+    for key in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "comm_ms", "overlap_frac"):
+        assert key in ln
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    rc, lines, err = _run_bench(["--gpus", "2", "--dry-run"], env_extra={"WORLD_SIZE": "1", "RANK": "0"})
+    assert rc != 0 and not lines

@@ -83,23 +83,24 @@ class SyntheticBatches:
 
 
 class ResidentBatches:
-    """One epoch's index batches over a `vitpe.data.ResidentDataset` (reference DataLoader(shuffle=...),
-    train.py:89-90): the loop hands the engine sample indices, the pixels never leave HBM."""
+    """One epoch's index batches over a `vitpe.data.ResidentDataset` (reference DataLoader(batch_size, shuffle=...),
+    train.py:89-90, no drop_last): the loop hands the engine sample indices, the pixels never leave HBM.  Yields
+    (idx, n_local, n_global) per GLOBAL batch; the ragged last batch is kept, as in the reference."""
 
-    def __init__(self, dataset, batch, shuffle, seed, rank, world):
-        self.ds, self.batch, self.shuffle, self.seed, self.rank, self.world = dataset, batch, shuffle, seed, rank, world
+    def __init__(self, dataset, global_batch, shuffle, seed, rank, world):
+        self.ds, self.global_batch, self.shuffle, self.seed = dataset, global_batch, shuffle, seed
+        self.rank, self.world = rank, world
         self.epoch = 0
 
     def __len__(self):
-        return (len(self.ds) // self.world) // self.batch
+        return (len(self.ds) + self.global_batch - 1) // self.global_batch
 
     def __iter__(self):
-        from vitpe.data import epoch_batches
-        it = epoch_batches(len(self.ds), self.batch, self.epoch, self.seed, self.shuffle, self.rank, self.world,
-                           self.ds.device)
+        from vitpe.data import epoch_global_batches
+        it = epoch_global_batches(len(self.ds), self.global_batch, self.epoch, self.seed, self.shuffle, self.rank,
+                                  self.world, self.ds.device)
         self.epoch += 1
-        for idx in it:
-            yield idx, None
+        return it
 
 
 def get_dataset(args, info, per_rank_batch, device, rank, world=1):
@@ -114,8 +115,8 @@ def get_dataset(args, info, per_rank_batch, device, rank, world=1):
         except VitpeError as e:
             raise SystemExit(f"{e}\nno dataset under {args.data_dir} (nothing is downloaded here): "
                              f"place the binary files there or re-run with --synthetic")
-        return (ResidentBatches(tr, per_rank_batch, True, args.seed, rank, world),
-                ResidentBatches(te, per_rank_batch, False, args.seed, rank, world))
+        return (ResidentBatches(tr, args.batch_size, True, args.seed, rank, world),
+                ResidentBatches(te, args.batch_size, False, args.seed, rank, world))
     n_train = args.steps_per_epoch or info['train'] // args.batch_size
     n_test = max(1, min(n_train // 5, info['test'] // args.batch_size))
     mk = lambda n, seed: SyntheticBatches(n, per_rank_batch, info['in_chans'], args.img_size,  # noqa: E731
@@ -124,35 +125,45 @@ def get_dataset(args, info, per_rank_batch, device, rank, world=1):
 
 
 def train(engine, loader):
-    """One epoch (reference train.py:94-125) -> (avg_loss, acc%). No per-step host sync."""
+    """One epoch (reference train.py:94-125) -> (avg_loss, acc%) over ALL ranks' samples. No per-step host sync."""
     seen = 0
     resident = isinstance(loader, ResidentBatches)
-    if resident:
-        engine.attach_dataset(loader.ds)
-    for images, labels in loader:
+    engine.attach_dataset(loader.ds if resident else None)
+    for item in loader:
         if resident:
-            engine.step_indexed(images)
+            idx, n_local, n_global = item
+            engine.step_indexed(idx, n_global, n_valid=n_local)
+            seen += n_global
         else:
+            images, labels = item
             engine.step(images, labels)
-        seen += images.shape[0]
-    loss_sum, correct = engine.read_metrics()
+            seen += images.shape[0] * engine.world
+    loss_sum, correct = engine.read_metrics()      # global-batch means summed over the steps; all ranks' #correct
     return loss_sum / max(len(loader), 1), 100. * correct / max(seen, 1)
 
 
 def test(engine, loader):
-    """Evaluation (reference train.py:127-155): forward only on the same kernels."""
-    from vitpe import kernels as K
-    loss_sum, correct, seen = 0.0, 0.0, 0
+    """Evaluation (reference train.py:127-155): forward only on the same kernels, every sample of the set counted
+    (ragged last batch included), totals summed over the ranks."""
+    seen = 0
     acc = torch.zeros(2, device=engine.dev)
     resident = isinstance(loader, ResidentBatches)
-    for images, labels in loader:
+    if not resident:
+        engine.attach_dataset(None)
+    for item in loader:
         if resident:
-            logits, labels = engine.forward_indexed(images, loader.ds), engine.labels
+            idx, n_local, n_global = item
+            engine.forward_indexed(idx, loader.ds)
+            engine.eval_loss(n_local, acc, n_global)
+            seen += n_global
         else:
-            logits = engine.forward_only(images)
-        out2, _ = K.cross_entropy(logits, labels, want_grad=False)
-        acc += out2
-        seen += images.shape[0]
+            images, labels = item
+            engine.forward_only(images)
+            engine.labels.copy_(labels)
+            engine.eval_loss(images.shape[0], acc, images.shape[0] * engine.world)
+            seen += images.shape[0] * engine.world
+    if engine.world > 1:
+        torch.distributed.all_reduce(acc)
     loss_sum, correct = acc.tolist()
     return loss_sum / max(len(loader), 1), 100. * correct / max(seen, 1)
 

@@ -184,12 +184,23 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
 
 // mean cross-entropy + dlogits = (softmax - onehot) * gscale ; single workgroup, fixed order.
 // out[0] = mean loss, out[1] = #correct (argmax == label)   (train.py:113,119-121)
+// ctl (nullable, device): {grad_scale, loss_scale, n_valid} -- read on the device so that a captured graph follows a
+// ragged last batch (reference train.py:89-90: no drop_last): rows b >= n_valid are padding, they get dlogits = 0
+// (every downstream gradient is linear in dlogits, so padded images contribute exactly nothing) and are left out of
+// the loss / accuracy.  out[0] = loss_scale * sum of the valid rows' losses.  acc (nullable): out is also added to it.
 __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
                                                  float* __restrict__ dlogits, float* __restrict__ out, int B, int Cn,
-                                                 float gscale) {
+                                                 float gscale, const float* __restrict__ ctl, float* __restrict__ acc) {
   __shared__ float sl[256], sc[256];
   float lsum = 0.f, csum = 0.f;
+  float lscale = 1.0f / (float)B;
+  int nvalid = B;
+  if (ctl != nullptr) { gscale = ctl[0]; lscale = ctl[1]; nvalid = min(B, (int)ctl[2]); }
   for (int b = threadIdx.x; b < B; b += 256) {
+    if (b >= nvalid) {
+      if (dlogits) for (int k = 0; k < Cn; ++k) dlogits[(size_t)b * Cn + k] = 0.f;
+      continue;
+    }
     const float* z = logits + (size_t)b * Cn;
     float m = z[0];
     int am = 0;
@@ -211,7 +222,11 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
     if (threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { out[0] = sl[0] / (float)B; out[1] = sc[0]; }
+  if (threadIdx.x == 0) {
+    const float l = sl[0] * lscale, c = sc[0];
+    out[0] = l; out[1] = c;
+    if (acc != nullptr) { acc[0] += l; acc[1] += c; }
+  }
 }
 
 // Training-step fusion of the three kernels above and below (classes <= 64): per image (one wave) the class row's
@@ -596,7 +611,14 @@ extern "C" int vitpe_head_fwd(int dtype, const void* x, const float* gamma, cons
 extern "C" int vitpe_cross_entropy(const float* logits, const long long* labels, float* dlogits, float* out2, int B,
                                    int Cn, float grad_scale, hipStream_t st) {
   VITPE_REQUIRE(logits && labels && out2 && B > 0 && Cn > 0);
-  hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(256), 0, st, logits, labels, dlogits, out2, B, Cn, grad_scale);
+  hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(256), 0, st, logits, labels, dlogits, out2, B, Cn, grad_scale,
+                     (const float*)nullptr, (float*)nullptr);
+  VITPE_CHECK_LAUNCH();
+}
+extern "C" int vitpe_cross_entropy_ctl(const float* logits, const long long* labels, float* dlogits, float* out2,
+                                       float* metric_acc, const float* ctl, int B, int Cn, hipStream_t st) {
+  VITPE_REQUIRE(logits && labels && out2 && ctl && B > 0 && Cn > 0);
+  hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(256), 0, st, logits, labels, dlogits, out2, B, Cn, 0.f, ctl, metric_acc);
   VITPE_CHECK_LAUNCH();
 }
 extern "C" int vitpe_head_bwd(int dtype, const float* dlogits, const float* Wh, const float* gamma,

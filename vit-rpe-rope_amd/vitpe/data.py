@@ -129,3 +129,32 @@ def epoch_batches(n_items: int, batch: int, epoch: int, seed: int = 0, shuffle: 
         yield mine[i * batch:(i + 1) * batch]
     if not drop_last and mine.numel() % batch:
         yield mine[nfull * batch:]
+
+
+def epoch_global_batches(n_items: int, global_batch: int, epoch: int, seed: int = 0, shuffle: bool = True, rank: int = 0,
+                         world: int = 1, device="cuda") -> Iterator[Tuple[torch.Tensor, int, int]]:
+    """The reference's DataLoader(batch_size=global_batch, shuffle=..., drop_last=False) (train.py:89-90) seen from
+    one rank: every GLOBAL batch k = order[k*G : (k+1)*G] (the last one ragged: 50000 % 128 = 80, 10000 % 128 = 16) is
+    cut into `world` contiguous shares of G / world slots; this rank gets the indices that fall into its share.
+    Yields (idx, n_local, n_global): idx int64 [max(n_local, 1)] on `device` (a rank whose share of a ragged batch is
+    empty still gets one index so that it runs the step -- the all-reduce needs every rank -- with n_local = 0),
+    n_global = size of the global batch.  Every sample of the dataset is visited exactly once per epoch and all ranks
+    make ceil(n_items / G) steps."""
+    if global_batch % world != 0:
+        raise ValueError(f"global batch {global_batch} is not divisible by world size {world}")
+    dev = torch.device(device)
+    if shuffle:
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed + epoch)
+        order = torch.randperm(n_items, generator=g, device=dev)
+    else:
+        order = torch.arange(n_items, device=dev)
+    per = global_batch // world
+    for k0 in range(0, n_items, global_batch):
+        n_global = min(global_batch, n_items - k0)
+        lo = min(rank * per, n_global)
+        hi = min((rank + 1) * per, n_global)
+        if hi > lo:
+            yield order[k0 + lo:k0 + hi], hi - lo, n_global
+        else:
+            yield order[k0:k0 + 1], 0, n_global

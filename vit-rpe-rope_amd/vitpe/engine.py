@@ -102,6 +102,7 @@ class TrainEngine:
             view.copy_(prm.data)
             prm.data = view
             prm.grad = self.flat_g[o:o + prm.numel()].view(prm.shape)
+        self.model.register_load_state_dict_post_hook(lambda _m, _keys: self.sync_from_model())
         self.hp = torch.zeros(16, **f)
         self.hp[:5] = torch.tensor([lr, betas[0], betas[1], eps, wd], **f)
         self.hp[8] = 1.0 / self.world
@@ -184,7 +185,12 @@ class TrainEngine:
                                  m2=f(M), r2=f(M), h=e(M, self.hid), u=e(M, self.hid)))
         self.logits, self.dlogits = f(B, self.Cn), f(B, self.Cn)
         self.out2 = f(2)
-        self.metric_acc = torch.zeros(2, dtype=torch.float32, device=dev)  # [sum of mean losses, #correct]
+        self.metric_acc = torch.zeros(2, dtype=torch.float32, device=dev)  # [sum of batch-mean losses, #correct]
+        # cross-entropy scalars live on the device so a captured step follows a ragged last batch (train.py:89-90):
+        # {grad_scale, loss_scale, n_valid}; see set_valid()
+        self.ce_ctl = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._valid = None
+        self.set_valid(B)
         self.head_scratch = torch.zeros(4, dtype=torch.float32, device=dev)
         # one-launch head + CE + head backward (vitpe_head_loss): measured 45 us against 40 us for the three small
         # kernels it replaces (one wave per image is a long serial chain) -- off unless VITPE_FUSE_HEAD=1
@@ -254,12 +260,7 @@ class TrainEngine:
                 nxt = (self.act[l + 1]["m1"], self.act[l + 1]["r1"]) if l + 1 < self.Lyr else None
                 eps_next = mdl.blocks[min(l + 1, self.Lyr - 1)].norm1.eps
                 if self.fuse_mlp and self.fuse_tail:   # proj + residual + LN2 + MLP branch: one kernel per block tail
-                    K.block_tail_fwd(a["a"].view(M, D), xin.view(M, D), self.Sh(blk.attn.proj.weight),
-                                     blk.attn.proj.bias.data, blk.norm2.weight.data, blk.norm2.bias.data,
-                                     self.Sh(blk.mlp.fc1.weight), blk.mlp.fc1.bias.data, self.Sh(blk.mlp.fc2.weight),
-                                     blk.mlp.fc2.bias.data, x_mid=a["xmid"].view(M, D), mean2=a["m2"], rstd2=a["r2"],
-                                     xn_out=a["xn2"].view(M, D), u=a["u"], h=a["h"], out=self.x[l + 1].view(M, D),
-                                     stats=nxt, eps2=blk.norm2.eps, eps_next=eps_next)
+                    self._block_tail_fwd(l, blk, a, nxt)
                     continue
                 K.linear(a["a"].view(M, D), self.Sh(blk.attn.proj.weight), blk.attn.proj.bias.data,
                          epi=L.EPI_BIAS_RESID, resid=xin.view(M, D), out=a["xmid"].view(M, D), stats=(a["m2"], a["r2"]),
@@ -295,6 +296,30 @@ class TrainEngine:
             K.head_fwd(self.x[-1], mdl.norm.weight.data, mdl.norm.bias.data, mdl.head.weight.data, mdl.head.bias.data,
                        mdl.norm.eps, save=True, logits=self.logits, ws=self.head_ws)
 
+    def _block_tail_fwd(self, l, blk, a, nxt):
+        M, D = self.M, self.D
+        eps_next = self.model.blocks[min(l + 1, self.Lyr - 1)].norm1.eps
+        K.block_tail_fwd(a["a"].view(M, D), self.x[l].view(M, D), self.Sh(blk.attn.proj.weight),
+                         blk.attn.proj.bias.data, blk.norm2.weight.data, blk.norm2.bias.data,
+                         self.Sh(blk.mlp.fc1.weight), blk.mlp.fc1.bias.data, self.Sh(blk.mlp.fc2.weight),
+                         blk.mlp.fc2.bias.data, x_mid=a["xmid"].view(M, D), mean2=a["m2"], rstd2=a["r2"],
+                         xn_out=a["xn2"].view(M, D), u=a["u"], h=a["h"], out=self.x[l + 1].view(M, D),
+                         stats=nxt, eps2=blk.norm2.eps, eps_next=eps_next)
+
+    def _block_tail_bwd(self, l, blk, a):
+        M, D, G = self.M, self.D, self.Gr
+        K.block_tail_bwd(self.dx_out[l + 1].view(M, D), a["u"], self.St(blk.mlp.fc2.weight), self.St(blk.mlp.fc1.weight),
+                         a["xmid"].view(M, D), a["m2"], a["r2"], blk.norm2.weight.data, G(blk.norm2.weight),
+                         G(blk.norm2.bias), self.St(blk.attn.proj.weight), du=self.du_l[l], out=self.dx_mid[l].view(M, D),
+                         da=self.dtmp.view(M, D))
+
+    def _tail_bytes(self, fwd: bool) -> int:
+        """Algorithmic HBM bytes of one block-tail launch (what the kernel must read and write once)."""
+        M, D, hid, es = self.M, self.D, self.hid, 2 if self.T == torch.bfloat16 else 4
+        if fwd:   # attention output + x in; x_mid, LN2(x_mid), x_out out (3 x [M,D]); u and h out (2 x [M,hid])
+            return (5 * M * D + 2 * M * hid) * es
+        return (4 * M * D + 2 * M * hid) * es   # dy, x_mid in; d x_mid, d attn out; u in, du out
+
     def _fwd_train(self):
         self._forward(head=not self.fuse_head)
 
@@ -305,9 +330,9 @@ class TrainEngine:
                         self.labels, self.logits, self.dlogits, self.head_ws, self.ws_dyn, self.dx_out[self.Lyr], self.out2,
                         self.metric_acc, self.head_scratch, G(mdl.head.weight), G(mdl.head.bias), G(mdl.norm.weight),
                         G(mdl.norm.bias), eps=mdl.norm.eps, grad_scale=1.0 / self.B)
-            return
-        K.cross_entropy(self.logits, self.labels, grad_scale=1.0 / self.B, dlogits=self.dlogits, out2=self.out2)
-        self.metric_acc.add_(self.out2)
+            return   # (experiment path, VITPE_FUSE_HEAD=1: full batches only)
+        K.cross_entropy_ctl(self.logits, self.labels, self.ce_ctl, dlogits=self.dlogits, out2=self.out2,
+                            metric_acc=self.metric_acc)
 
     def _wgrad_problems(self, lo, hi, with_embed):
         """(dY, X, dW, dbias) of every nn.Linear weight gradient of layers lo..hi (+ the patch embedding)."""
@@ -376,10 +401,7 @@ class TrainEngine:
             fc1_wgrad = lambda: K.gemm_tn(du, a["xn2"].view(M, D), G(blk.mlp.fc1.weight), G(blk.mlp.fc1.bias))  # noqa: E731
             tail_done = False
             if self.fuse_mlp and self.fuse_ln_bwd and self.fuse_tail:   # ... + the projection's data gradient
-                K.block_tail_bwd(dy, a["u"], self.St(blk.mlp.fc2.weight), self.St(blk.mlp.fc1.weight),
-                                 a["xmid"].view(M, D), a["m2"], a["r2"], blk.norm2.weight.data, G(blk.norm2.weight),
-                                 G(blk.norm2.bias), self.St(blk.attn.proj.weight), du=du, out=dmid3.view(M, D),
-                                 da=self.dtmp.view(M, D))
+                self._block_tail_bwd(l, blk, a)
                 self._wgrad(ev(), fc1_wgrad)
                 tail_done = True
             elif self.fuse_mlp and self.fuse_ln_bwd:   # gelu' + both data gradients + LayerNorm2 backward + residual
@@ -440,6 +462,24 @@ class TrainEngine:
         ddp.allreduce_sum_(self.flat_g, self.pg)
 
     # ---------------------------------------------------------------- public API
+    def set_valid(self, n_valid: int, n_valid_global: Optional[int] = None):
+        """The next steps' batches hold `n_valid` real samples in rows [0, n_valid) (the rest is padding) and the
+        GLOBAL batch (all ranks) holds `n_valid_global`.  Loss = mean over the global batch (train.py:113,194),
+        gradients = its gradient: dlogits are scaled by world / n_valid_global here and by 1 / world inside AdamW."""
+        if n_valid_global is None:
+            n_valid_global = n_valid * self.world
+        if not (0 <= n_valid <= self.B and n_valid_global >= max(n_valid, 1)):
+            raise L.VitpeError(f"set_valid({n_valid}, {n_valid_global}) with engine batch {self.B}")
+        if self._valid != (n_valid, n_valid_global):
+            self._valid = (n_valid, n_valid_global)
+            host = torch.tensor([self.world / n_valid_global, 1.0 / n_valid_global, float(n_valid), 0.0])
+            self.ce_ctl.copy_(host, non_blocking=False)
+
+    def sync_from_model(self):
+        """Re-derive every weight shadow (bf16 flat copy, transposed copies, packed qkv weights) from the fp32 master
+        parameters: call after editing parameters behind the engine's back (load_state_dict does it by itself)."""
+        self.refresh_shadows()
+
     def broadcast_parameters(self, src=0):
         """Initial parameter broadcast from rank 0 so all replicas start identical."""
         if self.world > 1:
@@ -498,43 +538,73 @@ class TrainEngine:
         self.graph_fb = self.graph_fb2 = self.graph_opt = None
 
     def _load_indices(self, idx: torch.Tensor, dataset=None):
+        """Sample indices of the next batch: [n] int64 with n <= B; a short (ragged last) batch is padded by repeating
+        its first index -- the padded rows are masked out of loss / accuracy / gradients by set_valid()."""
         dataset = dataset if dataset is not None else self.dataset
         if dataset is None:
             raise L.VitpeError("no dataset attached (TrainEngine.attach_dataset)")
-        if idx.shape != (self.B,) or idx.dtype != torch.int64:
-            raise L.VitpeError(f"expected {self.B} int64 sample indices, got {tuple(idx.shape)} {idx.dtype}")
-        self.batch_idx.copy_(idx, non_blocking=True)
+        n = idx.shape[0] if idx.dim() == 1 else -1
+        if not (1 <= n <= self.B) or idx.dtype != torch.int64:
+            raise L.VitpeError(f"expected 1..{self.B} int64 sample indices, got {tuple(idx.shape)} {idx.dtype}")
+        if n < self.B:
+            self.batch_idx.fill_(idx[0])
+            self.batch_idx[:n].copy_(idx, non_blocking=True)
+        else:
+            self.batch_idx.copy_(idx, non_blocking=True)
         torch.index_select(dataset.labels, 0, self.batch_idx, out=self.labels)
+        return n
 
-    def step_indexed(self, idx: torch.Tensor):
-        """One training step on samples `idx` [B] (int64, device) of the attached resident dataset."""
-        self._load_indices(idx)
+    def step_indexed(self, idx: torch.Tensor, n_valid_global: Optional[int] = None, n_valid: Optional[int] = None):
+        """One training step on samples `idx` [n <= B] (int64, device) of the attached resident dataset.  A ragged
+        batch (n < B; the reference DataLoader has no drop_last, train.py:89-90) runs through the same captured
+        graph with the padding masked on the device.  `n_valid_global`: size of the global batch over all ranks
+        (default n * world); `n_valid` < n marks trailing indices as padding too (a rank with an empty share)."""
+        n = self._load_indices(idx)
+        self.set_valid(n if n_valid is None else min(n, n_valid), n_valid_global)
         self.step()
 
     def forward_indexed(self, idx: torch.Tensor, dataset=None) -> torch.Tensor:
-        """Logits for samples `idx` of `dataset` (default: the attached one), eager forward (evaluation); the
-        labels land in `self.labels`.  Another dataset does not disturb the captured training graphs."""
+        """Logits [n, classes] for samples `idx` [n <= B] of `dataset` (default: the attached one), eager forward
+        (evaluation); the labels land in `self.labels[:n]`.  Another dataset does not disturb the captured graphs."""
         keep = self.dataset
         if dataset is not None:
             if self.batch_idx is None:
                 self.batch_idx = torch.zeros(self.B, dtype=torch.int64, device=self.dev)
             self.dataset = dataset
         try:
-            self._load_indices(idx)
+            n = self._load_indices(idx)
             self._forward()
         finally:
             self.dataset = keep
-        return self.logits
+        return self.logits[:n]
 
-    def step(self, images: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None):
-        """One training step (train.py:109-116).  `images` [B,C,S,S] fp32 / `labels` [B] int64 on the
-        device; None re-uses the resident batch.  No host synchronisation."""
-        if images is not None:
-            if images.shape[0] != self.B:
-                raise L.VitpeError(f"engine was built for batch {self.B}, got {images.shape[0]} "
-                                   "(use train_step_eager for ragged batches)")
+    def _load_batch(self, images, labels):
+        n = images.shape[0]
+        if not (1 <= n <= self.B) or tuple(images.shape[1:]) != tuple(self.images.shape[1:]):
+            raise L.VitpeError(f"engine was built for batches of up to {self.B} x {tuple(self.images.shape[1:])}, "
+                               f"got {tuple(images.shape)}")
+        if n < self.B:   # ragged batch: pad with copies of its first image (masked by set_valid)
+            self.images.copy_(images[:1].expand_as(self.images))
+            self.images[:n].copy_(images, non_blocking=True)
+            if labels is not None:
+                self.labels.fill_(0)
+                self.labels[:n].copy_(labels, non_blocking=True)
+        else:
             self.images.copy_(images, non_blocking=True)
-            self.labels.copy_(labels, non_blocking=True)
+            if labels is not None:
+                self.labels.copy_(labels, non_blocking=True)
+        return n
+
+    def step(self, images: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
+             n_valid_global: Optional[int] = None, exchange: bool = True):
+        """One training step (train.py:109-116).  `images` [n,C,S,S] fp32 / `labels` [n] int64 on the device with
+        n <= B (a ragged last batch is padded and masked, see set_valid); None re-uses the resident batch.  No host
+        synchronisation.  `exchange=False` skips the gradient all-reduce (measurement of the exposed communication
+        time only: the replicas diverge)."""
+        if images is not None:
+            if self.dataset is not None:
+                raise L.VitpeError("a resident dataset is attached: use step_indexed (or attach_dataset(None))")
+            self.set_valid(self._load_batch(images, labels), n_valid_global)
         if self.use_graph:
             if self.graph_fb is None:
                 self.capture()
@@ -542,15 +612,21 @@ class TrainEngine:
             if self.world > 1:
                 if self.overlap_comm:
                     # bucket 1 (upper layers + head) is exchanged while the lower layers' backward runs
-                    w1 = dist.all_reduce(self.flat_g[self.bucket_off:], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                    w1 = w2 = None
+                    if exchange:
+                        w1 = dist.all_reduce(self.flat_g[self.bucket_off:], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
                     self.graph_fb2.replay()
-                    w2 = dist.all_reduce(self.flat_g[:self.bucket_off], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-                    w1.wait(); w2.wait()
-                else:
+                    if exchange:
+                        w2 = dist.all_reduce(self.flat_g[:self.bucket_off], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                        w1.wait(); w2.wait()
+                elif exchange:
                     self._allreduce()
                 self.graph_opt.replay()
         else:
-            self._fwd_train(); self._loss(); self._backward(); self._allreduce(); self._optimizer()
+            self._fwd_train(); self._loss(); self._backward()
+            if exchange:
+                self._allreduce()
+            self._optimizer()
         self.steps_done += 1
 
     def forward_backward(self):
@@ -558,13 +634,88 @@ class TrainEngine:
         self._fwd_train(); self._loss(); self._backward()
 
     def forward_only(self, images: torch.Tensor) -> torch.Tensor:
-        self.images.copy_(images)
+        """Logits [n, classes] of `images` [n <= B, C, S, S] (eager forward on the same kernels)."""
+        if self.dataset is not None:
+            raise L.VitpeError("a resident dataset is attached: use forward_indexed (or attach_dataset(None))")
+        n = self._load_batch(images, None)
         self._forward()
-        return self.logits
+        return self.logits[:n]
+
+    def kernel_probes(self):
+        """The heavy kernels of the step as (name, [one launch closure per layer], algorithmic flop, algorithmic HBM
+        bytes per launch) on the engine's OWN per-layer operands, in the variants the step runs (LayerNorm-fused
+        attention with the xn side output, block tails, grouped weight gradients): bench.py rotates over the layers'
+        buffers so that no launch finds its input in L2, and prices each against min(MFMA peak, HBM peak x AI).
+        Gradients accumulate garbage meanwhile: callers zero flat_g afterwards."""
+        mdl, M, D, B, N, Hh, hid = self.model, self.M, self.D, self.B, self.N, self.H, self.hid
+        G, es = self.Gr, 2 if self.T == torch.bfloat16 else 4
+        hd = D // Hh
+        probes = []
+        attn_core_flop = 2 * 2 * N * N * hd * Hh * B
+        qkv_flop = 2 * M * D * 3 * D
+        if self.attn_fused:
+            def fwd(l):
+                blk, a = mdl.blocks[l], self.act[l]
+                if self.fuse_ln:
+                    return lambda: K.fused_attention_fwd(self.x[l], self.Pk(blk.attn.qkv.weight), Hh, self.pe, out=a["a"],
+                                                         ln=(blk.norm1.weight.data, blk.norm1.bias.data, a["m1"], a["r1"]),
+                                                         xn_out=a["xn1"])
+                return lambda: K.fused_attention_fwd(a["xn1"], self.Pk(blk.attn.qkv.weight), Hh, self.pe, out=a["a"])
+            def bwd(l):
+                blk, a = mdl.blocks[l], self.act[l]
+                return lambda: K.fused_attention_bwd(a["xn1"], self.Pk(blk.attn.qkv.weight), self.dx_mid[l], Hh, self.pe,
+                                                     out=self.dqkv_l[l], **self.pe_grads)
+            probes.append(dict(name="attn_fwd", kernel="attn_fwd_kernel (fused LN1+QKV-project+RoPE+QK^T+softmax+AV)",
+                               fns=[fwd(l) for l in range(self.Lyr)], flop=qkv_flop + attn_core_flop,
+                               bytes=2 * M * D * es))           # x in, merged heads out (SURVEY 8d: 49 920 B / image)
+            probes.append(dict(name="attn_bwd", kernel="attn_bwd_kernel (recompute + dQ/dK/dV + PE gradients -> d_qkv)",
+                               fns=[bwd(l) for l in range(self.Lyr)], flop=2 * (qkv_flop + attn_core_flop),
+                               bytes=(2 + 3) * M * D * es))     # xn, dout in; d_qkv out
+        else:
+            probes.append(dict(name="attn_fwd", kernel="attn_core_fwd_kernel (RoPE+QK^T+softmax+AV per (image, head))",
+                               fns=[(lambda l=l: K.attention_core_fwd(self.qkv_l[l], Hh, self.pe, out=self.act[l]["a"]))
+                                    for l in range(self.Lyr)], flop=attn_core_flop, bytes=4 * M * D * es))
+            probes.append(dict(name="attn_bwd", kernel="attn_core_bwd_kernel",
+                               fns=[(lambda l=l: K.attention_core_bwd(self.qkv_l[l], self.dx_mid[l], Hh, self.pe,
+                                                                      out=self.dqkv_l[l], **self.pe_grads))
+                                    for l in range(self.Lyr)], flop=2 * attn_core_flop, bytes=(3 + 1 + 3) * M * D * es))
+        if self.fuse_mlp and self.fuse_ln_bwd and self.fuse_tail and self.group_wgrad:
+            def tail_f(l):
+                blk, a = mdl.blocks[l], self.act[l]
+                nxt = (self.act[l + 1]["m1"], self.act[l + 1]["r1"]) if l + 1 < self.Lyr else None
+                return lambda: self._block_tail_fwd(l, blk, a, nxt)
+            def tail_b(l):
+                blk, a = mdl.blocks[l], self.act[l]
+                return lambda: self._block_tail_bwd(l, blk, a)
+            tail_flop = 2 * M * D * D + 2 * 2 * M * D * hid
+            probes.append(dict(name="block_tail_fwd", kernel="mlp_fwd_kernel (proj+residual+LN2+fc1+GELU+fc2+residual+stats)",
+                               fns=[tail_f(l) for l in range(self.Lyr)], flop=tail_flop,
+                               bytes=self._tail_bytes(fwd=True)))
+            probes.append(dict(name="block_tail_bwd", kernel="mlp_fwd_kernel<BWD> (gelu'+dgrad fc2/fc1+LN2 bwd+residual+dgrad proj)",
+                               fns=[tail_b(l) for l in range(self.Lyr)], flop=tail_flop,
+                               bytes=self._tail_bytes(fwd=False)))
+            self._wgrad_group("all") if "all" not in self._wg_groups else None
+            wg_flop = sum(2 * dy.shape[0] * dy.shape[1] * x.shape[1] for grp in self._wg_groups["all"] for dy, x, _, _ in grp.keep)
+            wg_bytes = sum((dy.numel() + x.numel()) * es + dw.numel() * 4 for grp in self._wg_groups["all"] for dy, x, dw, _ in grp.keep)
+            probes.append(dict(name="wgrad_group", kernel="wgrad_group_kernel (every nn.Linear weight gradient, one launch)",
+                               fns=[lambda: self._wgrad_group("all")], flop=wg_flop, bytes=wg_bytes))
+        return probes
+
+    def eval_loss(self, n: int, acc: torch.Tensor, n_global: Optional[int] = None):
+        """acc[0] += (sum of the cross-entropy of rows [0, n) of the current logits vs self.labels) / n_global (this
+        rank's part of the batch mean, reference train.py:146-149; n_global defaults to n), acc[1] += #correct.
+        Device-side; leaves the training scalars untouched."""
+        ctl = torch.tensor([0.0, 1.0 / max(n_global or n, 1), float(n), 0.0], device=self.dev)
+        K.cross_entropy_ctl(self.logits, self.labels, ctl, dlogits=None, out2=self.out2, metric_acc=acc)
 
     def read_metrics(self, reset=True):
-        """(mean loss over the steps since the last read, #correct) -- the ONLY host sync."""
-        v = self.metric_acc.tolist()
+        """(sum over the steps since the last read of the global-batch mean loss, #correct over all ranks) -- the
+        ONLY host sync (and, data parallel, one 2-float all-reduce per read: every rank must call it)."""
+        t = self.metric_acc
+        if self.world > 1:
+            t = self.metric_acc.clone()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+        v = t.tolist()
         if reset:
             self.metric_acc.zero_()
         return v[0], v[1]

@@ -492,6 +492,19 @@ def cross_entropy(logits, labels, grad_scale=None, dlogits=None, out2=None, want
     return o, dlogits
 
 
+def cross_entropy_ctl(logits, labels, ctl, dlogits=None, out2=None, metric_acc=None):
+    """cross_entropy with {grad_scale, loss_scale, n_valid} read from the device tensor `ctl` (float32[>=3]): rows
+    >= n_valid are padding (dlogits 0, not counted); out2 = [loss_scale * sum of losses, #correct]; metric_acc += out2."""
+    require_device(logits, labels, ctl, dlogits, out2, metric_acc)
+    B, Cn = logits.shape
+    assert labels.dtype == torch.int64 and ctl.dtype == torch.float32 and ctl.numel() >= 3
+    _f32(dlogits, "dlogits"), _f32(out2, "out2"), _f32(metric_acc, "metric_acc")
+    o = out2 if out2 is not None else torch.empty(2, dtype=torch.float32, device=logits.device)
+    check(lib().vitpe_cross_entropy_ctl(ptr(logits), ptr(labels), ptr(dlogits), ptr(o), ptr(metric_acc), ptr(ctl), B, Cn,
+                                        stream_ptr()), "vitpe_cross_entropy_ctl")
+    return o, dlogits
+
+
 def head_bwd(dlogits, wh, gamma, ws, dtype, Ntok, dwh, dbh, dgamma, dbeta, dx=None, ws_dyn=None):
     require_device(dlogits, wh, gamma, dwh, dbh, dgamma, dbeta, dx, ws_dyn)
     B, Cn = dlogits.shape
