@@ -227,6 +227,14 @@ int vitpe_rope_mixed_tables(const float* freqs, float* cosv, float* sinv, int H,
 int vitpe_relative_bias(const float* table, float* out, int H, int L, vitpe_stream_t stream); /* :82-95 */
 int vitpe_polynomial_bias(const float* coeff, float* out, int H, int G, int degree, int per_head,
                           vitpe_stream_t stream);                                  /* :127-171 */
+/* transposes of the three builders above (autograd of the stand-alone modules' get_bias() / get_freqs_cis(), which
+ * the reference returns as differentiable tensors): dtable [H,2L-1], dcoeff [deg+1] or [H,deg+1], dfreqs [2,H,half]
+ * are OVERWRITTEN with the gradient w.r.t. the parameter given d bias [H,L,L] resp. d cos / d sin [H,P,half].       */
+int vitpe_relative_bias_bwd(const float* dbias, float* dtable, int H, int L, vitpe_stream_t stream);
+int vitpe_polynomial_bias_bwd(const float* dbias, float* dcoeff, int H, int G, int degree, int per_head,
+                              vitpe_stream_t stream);
+int vitpe_rope_mixed_tables_bwd(const float* freqs, const float* dcos, const float* dsin, float* dfreqs, int H,
+                                int G, int half, vitpe_stream_t stream);
 /* models/rope_utils.py:3-37 on x [B,H,P,HD] fp32 (called once for q, once for k)              */
 int vitpe_apply_rotary(const float* x, float* y, const float* cosv, const float* sinv, int B, int H,
                        int P, int HD, int per_head, vitpe_stream_t stream);
@@ -274,17 +282,7 @@ int vitpe_transpose_cast(int dtype, const float* src, void* dst, int R, int C, v
 int vitpe_refresh_shadows(int dtype, const float* flat, void* dst_base, const void* desc, int ndesc,
                           int total_tiles, vitpe_stream_t stream);
 
-/* ---- primitive self-test (MFMA operand maps, transposed LDS read) ------------------------- */
-int vitpe_selftest_mma(int dtype, const void* A, const void* Bt, const void* Brow, float* C_row,
-                       float* C_tr, vitpe_stream_t stream);
-
-/* debug: resident workgroups/CU the runtime computes for attention kernel `which` (0 fwd rope, 1 fwd plain, 2 bwd rope) */
-int vitpe_debug_attn_occupancy(int which);
-/* debug census: bf16 D=192 plain forward; census[3*wg] = {hw_id|xcc<<32, t_start, t_end} (100 MHz ticks) */
-int vitpe_debug_wgrad_census(int dtype, const vitpe_wgrad_problem* problems, int nprob, unsigned long long* census,
-                             vitpe_stream_t stream);
-int vitpe_debug_attn_census(const void* xn, const void* wqkv, void* out, int B, unsigned long long* census,
-                            vitpe_stream_t stream);
+/* Self-tests and residency / phase-census instrumentation are NOT part of this boundary: include/vitpe_debug.h. */
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,27 @@
+/* vitpe_debug.h -- developer instrumentation exported by libvitpe.so next to the product ABI (include/vitpe.h).
+ * Nothing here is on the hot path or part of the drop-in boundary: primitive self-tests of the MFMA operand maps and
+ * the residency / phase-census launches used by tools/census*.py.  The census variants are separate template
+ * instantiations; the product kernels carry no stamps.                                                             */
+#ifndef VITPE_DEBUG_H
+#define VITPE_DEBUG_H
+#include "vitpe.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- primitive self-test (MFMA operand maps, transposed LDS read) ------------------------- */
+int vitpe_selftest_mma(int dtype, const void* A, const void* Bt, const void* Brow, float* C_row,
+                       float* C_tr, vitpe_stream_t stream);
+
+/* debug: resident workgroups/CU the runtime computes for attention kernel `which` (0 fwd rope, 1 fwd plain, 2 bwd rope) */
+int vitpe_debug_attn_occupancy(int which);
+/* debug census: bf16 D=192 plain forward; census[3*wg] = {hw_id|xcc<<32, t_start, t_end} (100 MHz ticks) */
+int vitpe_debug_wgrad_census(int dtype, const vitpe_wgrad_problem* problems, int nprob, unsigned long long* census,
+                             vitpe_stream_t stream);
+int vitpe_debug_attn_census(const void* xn, const void* wqkv, void* out, int B, unsigned long long* census,
+                            vitpe_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITPE_DEBUG_H */

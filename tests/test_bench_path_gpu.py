@@ -1,0 +1,342 @@
+"""End-to-end parity of the path bench.py times: the bf16 TrainEngine with its default fusions (LayerNorm-fused attention
+forward, block-tail forward / backward kernels, grouped weight gradients) INSIDE the captured HIP graph, at the full
+geometries of BASELINE.json -- logits, loss and EVERY parameter gradient against the CPU oracle (fp32, reference op
+order) evaluated on the same bf16-representable weights.
+
+The captured step ends in AdamW, which zeroes the gradient buffer; after the FIRST step the first moment is
+m = (1 - beta1) * g, so the gradients the graph computed are read back as flat_m / (1 - beta1).
+
+Tolerances (bf16 activations carry 8 significant bits through 6 resp. 12 layers; stated per check):
+  logits     max|a-b| / max|b| <= 5e-2
+  loss       |a-b| <= 2e-2
+  every grad max-norm rel <= 5e-2  AND  cosine >= 0.999
+  dWqkv / d table / d freqs / d coeff additionally per ROW: ||row_a - row_b||_2 <= 0.08 ||row_b||_2 + 0.01 max_row||row_b||_2
+  (the floor only admits rows whose whole norm is below 1 % of the largest row's -- they are dominated by rounding).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, rel_err
+from oracle import vit_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+MODES = [("none", {}), ("absolute", {}), ("relative", {}), ("polynomial", {}),
+         ("polynomial_perhead", {"pos_encoding": "polynomial", "poly_shared_heads": False}),
+         ("rope-axial", {}), ("rope-mixed", {})]
+ROW_CHECKED = ("attn.qkv.weight", "relative_position_bias_table", "pos_embed.freqs", "pos_embed.coefficients")
+
+
+def bf16_round_(model):
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(p.to(torch.bfloat16).to(torch.float32))
+
+
+def build(tag, extra, geom, seeded=False):
+    from models.vit import VisionTransformer
+    kw = dict(pos_encoding=extra.get("pos_encoding", tag))
+    kw.update({k: v for k, v in extra.items() if k != "pos_encoding"})
+    kw.update(geom)
+    cfg = O.VitConfig(**kw)
+    if seeded:
+        torch.manual_seed(0)
+    model = VisionTransformer(**kw)
+    if not seeded:
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                p.copy_(O.closed_form_tensor(n, tuple(p.shape), cfg))
+    bf16_round_(model)
+    return cfg, model.cuda()
+
+
+def cosine(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
+
+
+def row_check(a, b):
+    """worst over rows of (||a_r - b_r|| - 0.01 max_r ||b_r||) / ||b_r||: <= 0.08 passes."""
+    a = np.asarray(a, np.float64).reshape(-1, a.shape[-1])
+    b = np.asarray(b, np.float64).reshape(-1, b.shape[-1])
+    nb = np.linalg.norm(b, axis=1)
+    err = np.linalg.norm(a - b, axis=1) - 0.01 * nb.max()
+    return float(np.max(err / np.maximum(nb, 1e-300)))
+
+
+def graph_step_gradients(eng, images, labels):
+    """One captured-graph step; returns {name: gradient the graph computed} via the first Adam moment."""
+    assert eng.use_graph and eng.steps_done == 0
+    eng.step(images, labels)
+    torch.cuda.synchronize()
+    beta1 = float(eng.hp[1])
+    flat = (eng.flat_m / (1.0 - beta1)).cpu()
+    out = {}
+    for n, p in eng.model.named_parameters():
+        o = eng._off[id(p)]
+        out[n] = flat[o:o + p.numel()].view(p.shape)
+    return out
+
+
+def compare_all(tagname, model, grads, ref_grads, report):
+    """Fills report[tagname] with the worst figures and returns the list of violated checks (asserted by the caller
+    after the report has been written, so a failing run still leaves every number behind)."""
+    worst = {"rel": 0.0, "cos": 1.0, "row": 0.0}
+    bad = []
+    for n, p in model.named_parameters():
+        mine, ref = grads[n].numpy(), ref_grads[n].numpy()
+        if n == "pos_embed.pos_embed":                 # 5000 rows, only the first P receive gradient
+            if float(np.abs(mine[:, ref.shape[1]:]).max()) != 0.0:
+                bad.append((n, "unused rows", 0))
+            mine = mine[:, :ref.shape[1]]
+        if float(np.abs(ref).max()) == 0.0:
+            if float(np.abs(mine).max()) != 0.0:
+                bad.append((n, "nonzero", float(np.abs(mine).max())))
+            continue
+        r, c = rel_err(mine, ref), cosine(mine, ref)
+        if r > worst["rel"]:
+            worst["rel"], worst["rel_at"] = r, n
+        if c < worst["cos"]:
+            worst["cos"], worst["cos_at"] = c, n
+        if r > 5e-2:
+            bad.append((n, "rel", r))
+        if c < 0.999:
+            bad.append((n, "cos", c))
+        if any(k in n for k in ROW_CHECKED):
+            rc = row_check(mine if mine.ndim > 1 else mine[None], ref if ref.ndim > 1 else ref[None])
+            if rc > worst["row"]:
+                worst["row"], worst["row_at"] = rc, n
+            if rc > 0.08:
+                bad.append((n, "row", rc))
+    report[tagname] = worst
+    return bad
+
+
+def _dump(report, name):
+    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(REPO, "gpurun_out", name), "a") as f:
+        f.write(json.dumps(report) + "\n")
+
+
+@pytest.mark.parametrize("tag,extra", MODES)
+def test_bf16_captured_step_gradients_full_cifar_geometry(tag, extra):
+    """d=192, L=6, H=6 (BASELINE configs 2-4), B=16, bf16, default fusions, HIP graph: what bench.py times."""
+    from vitpe.engine import TrainEngine
+    cfg, model = build(tag, extra, {})
+    params = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+    if tag == "rope-axial":
+        params["pos_embed.inv_freq"] = model.pos_embed.inv_freq.cpu()
+    B = 16
+    images, labels = O.closed_form_batch(cfg, B, salt=3)
+    ref_logits, ref_loss, ref_grads = O.loss_and_grads(cfg, params, images, labels)
+    eng = TrainEngine(model, B, compute_dtype=torch.bfloat16, use_graph=True)
+    assert eng.attn_fused and eng.fuse_ln and eng.fuse_ln_bwd and eng.fuse_mlp and eng.fuse_tail and eng.group_wgrad
+    grads = graph_step_gradients(eng, images.cuda(), labels.cuda())
+    assert eng.graph_fb is not None
+    assert rel_err(eng.logits.cpu(), ref_logits) <= 5e-2
+    assert abs(float(eng.out2[0]) - float(ref_loss)) <= 2e-2
+    report = {}
+    bad = compare_all(tag, model, grads, ref_grads, report)
+    report[tag]["logits"] = rel_err(eng.logits.cpu(), ref_logits)
+    _dump(report, "bench_path_parity.jsonl")
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("tag,extra", [m for m in MODES if m[0] in ("rope-axial", "relative")])
+def test_bf16_captured_step_gradients_random_init(tag, extra):
+    """Same on the reference's own initialisation (trunc-normal / kaiming, vit.py:216-233) -- the weights bench.py
+    runs on -- with N(0,1) images."""
+    from vitpe.engine import TrainEngine
+    cfg, model = build(tag, extra, {}, seeded=True)
+    params = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+    if tag == "rope-axial":
+        params["pos_embed.inv_freq"] = model.pos_embed.inv_freq.cpu()
+    B = 16
+    g = torch.Generator().manual_seed(11)
+    images, labels = torch.randn(B, 3, 32, 32, generator=g), torch.randint(0, 10, (B,), generator=g)
+    ref_logits, ref_loss, ref_grads = O.loss_and_grads(cfg, params, images, labels)
+    eng = TrainEngine(model, B, compute_dtype=torch.bfloat16, use_graph=True)
+    grads = graph_step_gradients(eng, images.cuda(), labels.cuda())
+    assert rel_err(eng.logits.cpu(), ref_logits) <= 5e-2
+    assert abs(float(eng.out2[0]) - float(ref_loss)) <= 2e-2
+    report = {}
+    bad = compare_all(tag + "/random-init", model, grads, ref_grads, report)
+    _dump(report, "bench_path_parity.jsonl")
+    assert not bad, bad
+
+
+IMNET12 = dict(img_size=224, patch_size=16, embed_dim=768, depth=12, num_heads=12)
+
+
+def test_config5_twelve_layers_fp32_logits_and_bf16_gradients():
+    """BASELINE config 5 as stated (224/16, d=768, L=12, H=12, rope-axial), B=2: fp32 logits / loss at 1e-4 against the
+    oracle, then the bf16 captured step's gradients."""
+    from vitpe.engine import TrainEngine
+    cfg, model = build("rope-axial", {}, IMNET12, seeded=True)
+    params = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+    params["pos_embed.inv_freq"] = model.pos_embed.inv_freq.cpu()
+    B = 2
+    g = torch.Generator().manual_seed(5)
+    images, labels = torch.randn(B, 3, 224, 224, generator=g), torch.randint(0, 10, (B,), generator=g)
+    ref_logits, ref_loss, ref_grads = O.loss_and_grads(cfg, params, images, labels)
+    e32 = TrainEngine(model, B, compute_dtype=torch.float32, use_graph=False)
+    logits32 = e32.forward_only(images.cuda()).cpu()
+    assert rel_err(logits32, ref_logits) < 1e-4
+    e32.labels.copy_(labels.cuda())
+    e32._loss()
+    assert abs(float(e32.out2[0]) - float(ref_loss)) < 1e-4
+    del e32
+    # a fresh module on the same (bf16-representable) weights for the bf16 engine
+    cfg, model = build("rope-axial", {}, IMNET12, seeded=True)
+    eng = TrainEngine(model, B, compute_dtype=torch.bfloat16, use_graph=True)
+    grads = graph_step_gradients(eng, images.cuda(), labels.cuda())
+    assert rel_err(eng.logits.cpu(), ref_logits) <= 5e-2
+    report = {}
+    bad = compare_all("config5/L12", model, grads, ref_grads, report)
+    _dump(report, "bench_path_parity.jsonl")
+    assert not bad, bad
+
+
+# ------------------------------------------------------------------------------------------------ ragged batches
+SMALL = dict(embed_dim=96, depth=2, num_heads=3)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_ragged_batch_is_masked_exactly(use_graph):
+    """reference train.py:89-90 keeps the ragged last batch (50000 % 128 = 80): an engine built for B = 8 fed 5 samples
+    must produce the loss and the gradients of those 5 samples alone (fp32, vs the oracle), eager and captured."""
+    from vitpe.engine import TrainEngine
+    from models.vit import VisionTransformer
+    cfg = O.VitConfig(pos_encoding="relative", **SMALL)
+    model = VisionTransformer(pos_encoding="relative", **SMALL)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(O.closed_form_tensor(n, tuple(p.shape), cfg))
+    model.cuda()
+    params = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+    images, labels = O.closed_form_batch(cfg, 5, salt=4)
+    ref_logits, ref_loss, ref_grads = O.loss_and_grads(cfg, params, images, labels)
+    eng = TrainEngine(model, 8, compute_dtype=torch.float32, use_graph=use_graph)
+    if use_graph:
+        full_i, full_l = O.closed_form_batch(cfg, 8, salt=9)
+        grads = None
+        # a full batch first (captures the graph), parameters restored, then the ragged one through the SAME graph
+        snap = eng.flat_p.clone()
+        eng.step(full_i.cuda(), full_l.cuda())
+        eng.flat_p.copy_(snap); eng.flat_m.zero_(); eng.flat_v.zero_(); eng.hp[5:8] = 0; eng.sync_from_model()
+        eng.read_metrics()
+        eng.step(images.cuda(), labels.cuda())
+        torch.cuda.synchronize()
+        # first moment after one step from zero state: m = (1 - beta1) g
+        flat = (eng.flat_m / (1.0 - float(eng.hp[1]))).cpu()
+        grads = {n: flat[eng._off[id(p)]:eng._off[id(p)] + p.numel()].view(p.shape) for n, p in model.named_parameters()}
+        loss = eng.read_metrics()[0]
+    else:
+        eng._load_batch(images.cuda(), labels.cuda())
+        eng.set_valid(5)
+        eng.forward_backward()
+        grads = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()}
+        loss = float(eng.out2[0])
+    assert rel_err(eng.logits[:5].cpu(), ref_logits) < 1e-4
+    assert abs(loss - float(ref_loss)) < 1e-4
+    assert float(eng.dlogits[5:].abs().max()) == 0.0
+    for n, _ in model.named_parameters():
+        assert rel_err(grads[n], ref_grads[n]) < 1e-3, n
+
+
+def test_train_py_counts_every_sample_of_a_dataset_that_is_not_a_multiple_of_the_batch(tmp_path):
+    """train.py's loops on CIFAR-format files with 203 train / 70 test records, batch 32: 7 / 3 steps per epoch, the
+    evaluation covers all 70 images (loss = mean of the batch means, accuracy over 70) -- reference train.py:127-155."""
+    import train as T
+    from vitpe.data import ResidentDataset
+    from vitpe.engine import TrainEngine
+    from models.vit import VisionTransformer
+    rng = np.random.default_rng(1)
+    n_tr, n_te, Bt = 203, 70, 32
+    mean, std = O.DATASET_STATS["cifar10"]
+    mk = lambda n: (torch.from_numpy(rng.integers(0, 256, (n, 3, 32, 32), dtype=np.uint8)),  # noqa: E731
+                    torch.from_numpy(rng.integers(0, 10, n)))
+    (xtr, ytr), (xte, yte) = mk(n_tr), mk(n_te)
+    tr = T.ResidentBatches(ResidentDataset(xtr, ytr, mean, std, "cuda"), Bt, True, 0, 0, 1)
+    te = T.ResidentBatches(ResidentDataset(xte, yte, mean, std, "cuda"), Bt, False, 0, 0, 1)
+    assert len(tr) == 7 and len(te) == 3
+    cfg = O.VitConfig(pos_encoding="rope-axial", **SMALL)
+    model = VisionTransformer(pos_encoding="rope-axial", **SMALL)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(O.closed_form_tensor(n, tuple(p.shape), cfg))
+    model.cuda()
+    eng = TrainEngine(model, Bt, compute_dtype=torch.float32, use_graph=True)
+    # evaluation against the oracle on all 70 images
+    params = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+    params["pos_embed.inv_freq"] = model.pos_embed.inv_freq.cpu()
+    with torch.no_grad():
+        ref = O.forward(cfg, params, O.normalize_u8(xte, mean, std))
+    ce = torch.nn.functional.cross_entropy
+    ref_loss = sum(float(ce(ref[i:i + Bt], yte[i:i + Bt])) for i in range(0, n_te, Bt)) / 3
+    ref_acc = 100.0 * float((ref.argmax(1) == yte).sum()) / n_te
+    loss, acc = T.test(eng, te)
+    assert abs(loss - ref_loss) < 1e-4 and abs(acc - ref_acc) < 1e-9
+    # one training epoch: 7 steps, 203 samples seen
+    steps0 = eng.steps_done
+    tl, ta = T.train(eng, tr)
+    assert eng.steps_done - steps0 == 7 and tl == tl and 0.0 <= ta <= 100.0
+    assert abs(ta * n_tr / 100.0 - round(ta * n_tr / 100.0)) < 1e-6       # the accuracy is a count over 203
+
+
+def test_load_state_dict_refreshes_the_engine_shadows():
+    from vitpe.engine import TrainEngine
+    from models.vit import VisionTransformer
+    torch.manual_seed(0)
+    model = VisionTransformer(pos_encoding="rope-axial", **SMALL).cuda()
+    eng = TrainEngine(model, 4, compute_dtype=torch.bfloat16, use_graph=False)
+    x = torch.randn(4, 3, 32, 32, device="cuda")
+    before = eng.forward_only(x).clone()
+    torch.manual_seed(1)
+    other = VisionTransformer(pos_encoding="rope-axial", **SMALL).cuda()
+    model.load_state_dict(other.state_dict())
+    after = eng.forward_only(x).clone()
+    fresh = TrainEngine(other, 4, compute_dtype=torch.bfloat16, use_graph=False).forward_only(x)
+    assert not torch.equal(before, after) and torch.equal(after, fresh)
+    from vitpe._lib import VitpeError
+    from vitpe.data import ResidentDataset
+    eng.attach_dataset(ResidentDataset(torch.zeros(8, 3, 32, 32, dtype=torch.uint8), torch.zeros(8, dtype=torch.int64),
+                                       (0.5,) * 3, (0.5,) * 3, "cuda"))
+    with pytest.raises(VitpeError):
+        eng.forward_only(x)            # a resident dataset is attached: the images argument would be ignored
+
+
+def test_standalone_pe_modules_are_differentiable_like_the_reference():
+    """get_bias() / get_freqs_cis() return autograd-tracked tensors in the reference (positional_encoding.py:82-95,
+    127-171,313-351; a visualizer or a custom loss may differentiate through them): gradients w.r.t. the table /
+    coefficients / frequencies against autograd over the oracle's restatement of the same functions."""
+    from models import positional_encoding as pe
+    H, P, hd = 6, 64, 32
+    g = torch.Generator().manual_seed(2)
+    # relative
+    r = pe.RelativePositionalEncoding(P, num_heads=H).cuda()
+    w = torch.randn(H, P + 1, P + 1, generator=g)
+    (r.get_bias() * w.cuda()).sum().backward()
+    t = r.relative_position_bias_table.detach().cpu().clone().requires_grad_(True)
+    (O.relative_bias(t, P + 1) * w).sum().backward()
+    assert rel_err(r.relative_position_bias_table.grad.cpu(), t.grad) < 1e-5
+    # polynomial, shared and per head
+    for shared in (True, False):
+        m = pe.PolynomialRPE(P, degree=3, num_heads=H, shared_across_heads=shared).cuda()
+        (m.get_bias() * w.cuda()).sum().backward()
+        c = m.coefficients.detach().cpu().clone().requires_grad_(True)
+        (O.polynomial_bias(c, P, H, 3, shared) * w).sum().backward()
+        assert rel_err(m.coefficients.grad.cpu(), c.grad) < 1e-5, shared
+    # rope-mixed through the view-scramble
+    x = pe.RoPEMixed(hd, H, 100.0).cuda()
+    wc, ws = torch.randn(H, P, hd // 2, generator=g), torch.randn(H, P, hd // 2, generator=g)
+    cos, sin = x.get_freqs_cis(P, torch.device("cuda"))
+    ((cos * wc.cuda()).sum() + (sin * ws.cuda()).sum()).backward()
+    f = x.freqs.detach().cpu().clone().requires_grad_(True)
+    oc, os_ = O.rope_mixed_tables(P, f)
+    ((oc * wc).sum() + (os_ * ws).sum()).backward()
+    assert rel_err(x.freqs.grad.cpu(), f.grad) < 1e-4

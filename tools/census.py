@@ -2,7 +2,7 @@ import os, sys, torch, collections
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vit-rpe-rope_amd"))
 from vitpe import _lib
-h=_lib.lib()
+h=_lib.debug_lib()
 B=int(os.environ.get("KB_B","512")); S=32
 xn=torch.randn(B,65,192,device="cuda").bfloat16(); from vitpe import kernels as K
 w=K.pack_qkv_weights(torch.randn(576,192,device="cuda")*0.1, torch.bfloat16, 6); out=torch.empty_like(xn)

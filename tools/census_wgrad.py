@@ -18,7 +18,7 @@ for _ in range(3):
     grp.launch()
 NWG, ST, SL = 512, 24, 4
 cen = torch.zeros(NWG * 12 * ST * SL, dtype=torch.int64, device="cuda")
-h = _lib.lib()
+h = _lib.debug_lib()
 e = h.vitpe_debug_wgrad_census(1, ctypes.addressof(grp.arr), len(grp.arr), cen.data_ptr(), torch.cuda.current_stream().cuda_stream)
 assert e == 0
 torch.cuda.synchronize()

@@ -125,6 +125,64 @@ __global__ void poly_bias_kernel(const float* __restrict__ coeff, float* out, in
   out[idx] = v;
 }
 
+// Transposes of the three table builders above, for the stand-alone modules' differentiable get_bias() /
+// get_freqs_cis() (the reference returns autograd-tracked tensors, positional_encoding.py:82-95,127-171,313-351).
+// Deterministic (fixed summation order), not on the hot path: inside the model the attention backward kernels
+// produce these gradients directly.
+__global__ void rel_bias_bwd_kernel(const float* __restrict__ dbias, float* __restrict__ dtable, int H, int L) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (h, r): the r-th diagonal i - j = r - (L-1)
+  if (idx >= H * (2 * L - 1)) return;
+  const int h = idx / (2 * L - 1), r = idx % (2 * L - 1);
+  float s = 0.f;
+  for (int i = 0; i < L; ++i) {
+    const int j = i - (r - (L - 1));
+    if (j >= 0 && j < L) s += dbias[((size_t)h * L + i) * L + j];
+  }
+  dtable[idx] = s;
+}
+// one workgroup per (head group, power k): dcoeff[hh][k] = sum_{h in group} sum_{i,j>=1} dbias[h,i,j] * l1(i,j)^k
+__global__ __launch_bounds__(256) void poly_bias_bwd_kernel(const float* __restrict__ dbias, float* __restrict__ dcoeff,
+                                                            int H, int G, int degree, int per_head) {
+  __shared__ float red[256];
+  const int P = G * G, L = P + 1;
+  const int hh = blockIdx.x / (degree + 1), k = blockIdx.x % (degree + 1);
+  const int h0 = per_head ? hh : 0, h1 = per_head ? hh + 1 : H;
+  float s = 0.f;
+  for (int h = h0; h < h1; ++h)
+    for (int q = threadIdx.x; q < P * P; q += 256) {
+      const int pi = q / P, pj = q % P;
+      const float x = (float)(abs(pi % G - pj % G) + abs(pi / G - pj / G));
+      float pw = 1.f;
+      for (int t = 0; t < k; ++t) pw *= x;
+      s += dbias[((size_t)h * L + pi + 1) * L + pj + 1] * pw;
+    }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dcoeff[blockIdx.x] = red[0];
+}
+// dfreqs[a][hs][f] = sum over the slots [h,n] the view-scramble maps to head hs of t_a(ps) * (cos*dsin - sin*dcos)
+__global__ void rope_mixed_bwd_kernel(const float* __restrict__ freqs, const float* __restrict__ dcos,
+                                      const float* __restrict__ dsin, float* __restrict__ dfreqs, int H, int G, int half) {
+  const int P = G * G;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 2 * H * half) return;
+  const int f = idx % half, hs = (idx / half) % H, a = idx / (half * H);
+  const float fx = freqs[(0 * H + hs) * half + f], fy = freqs[(1 * H + hs) * half + f];
+  float s = 0.f;
+  for (int ps = 0; ps < P; ++ps) {
+    const int flat = hs * P + ps, n = flat / H, h = flat % H;   // inverse of flat = n*H + h
+    const float tx = (float)(ps % G), ty = (float)(ps / G);
+    const float ph = __fadd_rn(__fmul_rn(tx, fx), __fmul_rn(ty, fy));
+    const size_t o = ((size_t)h * P + n) * half + f;
+    s += (a == 0 ? tx : ty) * (cosf(ph) * dsin[o] - sinf(ph) * dcos[o]);
+  }
+  dfreqs[idx] = s;
+}
+
 // stand-alone rotate-half (models/rope_utils.py:3-37): x [B,H,P,HD] fp32, cos/sin [P,HD/2] or [H,P,HD/2]
 __global__ void rotary_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ cosv,
                               const float* __restrict__ sinv, long long total_pairs, int H, int P, int half, int per_head) {
@@ -582,6 +640,24 @@ extern "C" int vitpe_polynomial_bias(const float* coeff, float* out, int H, int 
   VITPE_REQUIRE(coeff && out && H > 0 && G > 0 && degree >= 0);
   const int L = G * G + 1;
   hipLaunchKernelGGL(poly_bias_kernel, GRID1D(H * L * L), 0, st, coeff, out, H, G, degree, per_head);
+  VITPE_CHECK_LAUNCH();
+}
+extern "C" int vitpe_relative_bias_bwd(const float* dbias, float* dtable, int H, int L, hipStream_t st) {
+  VITPE_REQUIRE(dbias && dtable && H > 0 && L > 0);
+  hipLaunchKernelGGL(rel_bias_bwd_kernel, GRID1D(H * (2 * L - 1)), 0, st, dbias, dtable, H, L);
+  VITPE_CHECK_LAUNCH();
+}
+extern "C" int vitpe_polynomial_bias_bwd(const float* dbias, float* dcoeff, int H, int G, int degree, int per_head,
+                                         hipStream_t st) {
+  VITPE_REQUIRE(dbias && dcoeff && H > 0 && G > 0 && degree >= 0);
+  hipLaunchKernelGGL(poly_bias_bwd_kernel, dim3((per_head ? H : 1) * (degree + 1)), dim3(256), 0, st, dbias, dcoeff, H, G,
+                     degree, per_head);
+  VITPE_CHECK_LAUNCH();
+}
+extern "C" int vitpe_rope_mixed_tables_bwd(const float* freqs, const float* dcos, const float* dsin, float* dfreqs, int H,
+                                           int G, int half, hipStream_t st) {
+  VITPE_REQUIRE(freqs && dcos && dsin && dfreqs && H > 0 && G > 0 && half > 0);
+  hipLaunchKernelGGL(rope_mixed_bwd_kernel, GRID1D(2 * H * half), 0, st, freqs, dcos, dsin, dfreqs, H, G, half);
   VITPE_CHECK_LAUNCH();
 }
 extern "C" int vitpe_apply_rotary(const float* x, float* y, const float* cosv, const float* sinv, int B, int H, int P,

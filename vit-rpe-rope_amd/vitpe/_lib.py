@@ -17,6 +17,7 @@ PKG_ROOT = os.path.dirname(_HERE)                       # vit-rpe-rope_amd/
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libvitpe.so")
 HEADER_PATH = os.path.join(REPO_ROOT, "include", "vitpe.h")
+DEBUG_HEADER_PATH = os.path.join(REPO_ROOT, "include", "vitpe_debug.h")   # self-tests / census: not the product ABI
 
 F32, BF16 = 0, 1
 PE_CODES = {"none": 0, "absolute": 1, "relative": 2, "polynomial": 3, "rope-axial": 4, "rope-mixed": 5}
@@ -68,6 +69,18 @@ def lib():
             fn.restype = ctypes.c_int
         _lib = handle
     return _lib
+
+
+def debug_lib():
+    """The same library with the developer entry points of include/vitpe_debug.h bound as well (tests / tools only)."""
+    handle = lib()
+    if not getattr(handle, "_vitpe_debug_bound", False):
+        for name, argtypes in parse_header(DEBUG_HEADER_PATH).items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        handle._vitpe_debug_bound = True
+    return handle
 
 
 def check(err: int, what: str):

@@ -449,6 +449,34 @@ def polynomial_bias(coeff, H, grid, degree, per_head):
     return out
 
 
+def relative_bias_bwd(dbias, L_):
+    require_device(dbias)
+    _f32(dbias, "dbias")
+    H = dbias.shape[0]
+    out = torch.empty((H, 2 * L_ - 1), dtype=torch.float32, device=dbias.device)
+    check(lib().vitpe_relative_bias_bwd(ptr(dbias), ptr(out), H, L_, stream_ptr()), "vitpe_relative_bias_bwd")
+    return out
+
+
+def polynomial_bias_bwd(dbias, H, grid, degree, per_head):
+    require_device(dbias)
+    _f32(dbias, "dbias")
+    out = torch.empty((H, degree + 1) if per_head else (degree + 1,), dtype=torch.float32, device=dbias.device)
+    check(lib().vitpe_polynomial_bias_bwd(ptr(dbias), ptr(out), H, grid, degree, int(per_head), stream_ptr()),
+          "vitpe_polynomial_bias_bwd")
+    return out
+
+
+def rope_mixed_tables_bwd(freqs, dcos, dsin, grid):
+    require_device(freqs, dcos, dsin)
+    _f32(dcos, "dcos"), _f32(dsin, "dsin")
+    _, H, half = freqs.shape
+    out = torch.empty_like(freqs)
+    check(lib().vitpe_rope_mixed_tables_bwd(ptr(freqs), ptr(dcos), ptr(dsin), ptr(out), H, grid, half, stream_ptr()),
+          "vitpe_rope_mixed_tables_bwd")
+    return out
+
+
 def apply_rotary(x, cos, sin):
     """rope_utils.py:18-37 on one tensor x [B,H,P,HD] fp32."""
     require_device(x, cos, sin)
@@ -570,6 +598,6 @@ def selftest_mma(a, bt, brow):
     require_device(a, bt, brow)
     c_row = torch.empty((16, 16), dtype=torch.float32, device=a.device)
     c_tr = torch.empty((16, 16), dtype=torch.float32, device=a.device)
-    check(lib().vitpe_selftest_mma(dtype_code(a.dtype), ptr(a), ptr(bt), ptr(brow), ptr(c_row), ptr(c_tr),
+    check(L.debug_lib().vitpe_selftest_mma(dtype_code(a.dtype), ptr(a), ptr(bt), ptr(brow), ptr(c_row), ptr(c_tr),
                                    stream_ptr()), "vitpe_selftest_mma")
     return c_row, c_tr

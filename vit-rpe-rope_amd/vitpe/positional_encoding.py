@@ -14,6 +14,50 @@ import torch.nn as nn
 from . import kernels as K
 
 
+class _RelativeBias(torch.autograd.Function):
+    """bias = table[:, idx] with the scatter-add transpose (reference positional_encoding.py:82-95 under autograd)."""
+
+    @staticmethod
+    def forward(ctx, table, seq_length):
+        ctx.seq_length = seq_length
+        return K.relative_bias(table.contiguous(), seq_length)
+
+    @staticmethod
+    def backward(ctx, dbias):
+        return K.relative_bias_bwd(dbias.contiguous().float(), ctx.seq_length), None
+
+
+class _PolynomialBias(torch.autograd.Function):
+    """reference positional_encoding.py:127-171 under autograd."""
+
+    @staticmethod
+    def forward(ctx, coeff, num_heads, grid, degree, per_head):
+        ctx.cfg = (num_heads, grid, degree, per_head)
+        return K.polynomial_bias(coeff.contiguous(), num_heads, grid, degree, per_head)
+
+    @staticmethod
+    def backward(ctx, dbias):
+        return K.polynomial_bias_bwd(dbias.contiguous().float(), *ctx.cfg), None, None, None, None
+
+
+class _MixedTables(torch.autograd.Function):
+    """(cos, sin) of the view-scrambled phases (reference positional_encoding.py:313-351) under autograd."""
+
+    @staticmethod
+    def forward(ctx, freqs, grid):
+        freqs = freqs.contiguous()
+        ctx.save_for_backward(freqs)
+        ctx.grid = grid
+        return K.rope_mixed_tables(freqs, grid)
+
+    @staticmethod
+    def backward(ctx, dcos, dsin):
+        (freqs,) = ctx.saved_tensors
+        z = lambda t, like: torch.zeros_like(like) if t is None else t.contiguous().float()  # noqa: E731
+        cos_like = torch.empty((freqs.shape[1], ctx.grid * ctx.grid, freqs.shape[2]), device=freqs.device)
+        return K.rope_mixed_tables_bwd(freqs, z(dcos, cos_like), z(dsin, cos_like), ctx.grid), None
+
+
 class NoPositionalEncoding(nn.Module):
     """reference positional_encoding.py:5-21."""
 
@@ -66,8 +110,8 @@ class RelativePositionalEncoding(nn.Module):
         return x
 
     def get_bias(self):
-        """[H, L, L] = table[:, idx] (reference :82-95)."""
-        return K.relative_bias(self.relative_position_bias_table.detach().contiguous(), self.seq_length)
+        """[H, L, L] = table[:, idx] (reference :82-95), differentiable w.r.t. the table."""
+        return _RelativeBias.apply(self.relative_position_bias_table, self.seq_length)
 
 
 class PolynomialRPE(nn.Module):
@@ -88,9 +132,9 @@ class PolynomialRPE(nn.Module):
         return x
 
     def get_bias(self):
-        """[H, P+1, P+1], class row/column zero (reference :127-171)."""
-        return K.polynomial_bias(self.coefficients.detach().contiguous(), self.num_heads, self.grid_size,
-                                 self.degree, not self.shared_across_heads)
+        """[H, P+1, P+1], class row/column zero (reference :127-171), differentiable w.r.t. the coefficients."""
+        return _PolynomialBias.apply(self.coefficients, self.num_heads, self.grid_size, self.degree,
+                                     not self.shared_across_heads)
 
 
 class RoPEAxial(nn.Module):
@@ -144,6 +188,6 @@ class RoPEMixed(nn.Module):
 
     def get_freqs_cis(self, seq_len, device):
         """(cos, sin) each [H, seq_len, dim/2] fp32 (contiguous; same values as the reference's
-        strided view)."""
+        strided view), differentiable w.r.t. `freqs` like the reference's."""
         grid = int(math.sqrt(seq_len))
-        return K.rope_mixed_tables(self.freqs.detach().to(device).contiguous(), grid)
+        return _MixedTables.apply(self.freqs.to(device), grid)
