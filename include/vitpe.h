@@ -84,6 +84,14 @@ int vitpe_fused_attention_bwd(int dtype, const void* xn, const void* wqkv, const
                               const float* sin, const float* table, const float* coeff, int grid,
                               int degree, int coeff_per_head, float* dtable, float* dcoeff,
                               float* dfreqs, vitpe_stream_t stream);
+/* The same with the LayerNorm recomputed while staging: x = RAW tokens, mean / rstd their row statistics (as
+ * vitpe_fused_attention_fwd_ln) -- the forward then need not store LayerNorm(x) at all.                       */
+int vitpe_fused_attention_bwd_ln(int dtype, const void* x, const float* gamma, const float* beta,
+                                 const float* mean, const float* rstd, const void* wqkv, const void* dout,
+                                 void* dqkv, int B, int N, int D, int HD, int mode, const float* cos,
+                                 const float* sin, const float* table, const float* coeff, int grid,
+                                 int degree, int coeff_per_head, float* dtable, float* dcoeff,
+                                 float* dfreqs, vitpe_stream_t stream);
 
 /* ---- attention core on a qkv buffer (geometries the fused kernels do not cover) -----------
  * Replaces models/vit.py:49-92 between `qkv = self.qkv(x)` and `self.proj`: head split, RoPE on
@@ -173,7 +181,7 @@ int vitpe_block_tail_bwd(int dtype, const void* dy, const void* u, const void* W
 int vitpe_gemm_tn(int dtype, const void* dY, const void* X, float* dW, float* dbias, int M, int N,
                   int K, int splits, vitpe_stream_t stream);
 
-/* vitpe_wgrad_group: the same product for a LIST of independent problems (<= 32) in one launch --
+/* vitpe_wgrad_group: the same product for a LIST of independent problems (<= 28) in one launch --
  * e.g. every nn.Linear weight/bias gradient of the model (autograd's addmm backward in the
  * reference: vit.py:35,37 and timm Mlp fc1/fc2, once per block).  `problems` is a HOST array; the
  * descriptors travel as kernel arguments (no device table, graph-capture safe).  Work is cut into
@@ -184,8 +192,17 @@ typedef struct {
   const void* X;  /* [M,K] T */
   float* dW;      /* [N,K] fp32, accumulated into */
   float* dbias;   /* [N] fp32 or NULL, accumulated into */
-  int M, N, K, reserved;
+  int M, N, K;
+  int x_op;       /* VITPE_XOP_NONE, or VITPE_XOP_LAYERNORM: the operand is LayerNorm(X) with the row statistics and
+                   * affine parameters below, recomputed while staging (the normalised tensor is never stored: it is
+                   * a pure function of X, which the forward keeps anyway, vit.py:122,124) */
+  const float* x_mean;  /* [M] */
+  const float* x_rstd;  /* [M] */
+  const float* x_gamma; /* [K] */
+  const float* x_beta;  /* [K] */
 } vitpe_wgrad_problem;
+#define VITPE_XOP_NONE 0
+#define VITPE_XOP_LAYERNORM 1
 int vitpe_wgrad_group(int dtype, const vitpe_wgrad_problem* problems, int nprob, vitpe_stream_t stream);
 
 /* ---- LayerNorm (nn.LayerNorm(d), eps 1e-5: vit.py:113,116,210) ------------------------------ */

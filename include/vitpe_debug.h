@@ -15,12 +15,9 @@ int vitpe_selftest_mma(int dtype, const void* A, const void* Bt, const void* Bro
 
 /* debug: resident workgroups/CU the runtime computes for attention kernel `which` (0 fwd rope, 1 fwd plain, 2 bwd rope) */
 int vitpe_debug_attn_occupancy(int which);
-/* debug census: bf16 D=192 plain forward; census[3*wg] = {hw_id|xcc<<32, t_start, t_end} (100 MHz ticks) */
+/* phase census of the grouped weight-gradient kernel (a separate template instantiation with s_memtime stamps) */
 int vitpe_debug_wgrad_census(int dtype, const vitpe_wgrad_problem* problems, int nprob, unsigned long long* census,
                              vitpe_stream_t stream);
-int vitpe_debug_attn_census(const void* xn, const void* wqkv, void* out, int B, unsigned long long* census,
-                            vitpe_stream_t stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -60,12 +60,11 @@ def cosine(a, b):
 
 
 def row_check(a, b):
-    """worst over rows of (||a_r - b_r|| - 0.01 max_r ||b_r||) / ||b_r||: <= 0.08 passes."""
+    """worst over rows of (||a_r - b_r|| - 0.08 ||b_r||) / max_r ||b_r||: <= 0.01 passes."""
     a = np.asarray(a, np.float64).reshape(-1, a.shape[-1])
     b = np.asarray(b, np.float64).reshape(-1, b.shape[-1])
     nb = np.linalg.norm(b, axis=1)
-    err = np.linalg.norm(a - b, axis=1) - 0.01 * nb.max()
-    return float(np.max(err / np.maximum(nb, 1e-300)))
+    return float(np.max((np.linalg.norm(a - b, axis=1) - 0.08 * nb) / max(nb.max(), 1e-300)))
 
 
 def graph_step_gradients(eng, images, labels):
@@ -90,7 +89,7 @@ def compare_all(tagname, model, grads, ref_grads, report):
     for n, p in model.named_parameters():
         mine, ref = grads[n].numpy(), ref_grads[n].numpy()
         if n == "pos_embed.pos_embed":                 # 5000 rows, only the first P receive gradient
-            if float(np.abs(mine[:, ref.shape[1]:]).max()) != 0.0:
+            if mine.shape[1] > ref.shape[1] and float(np.abs(mine[:, ref.shape[1]:]).max()) != 0.0:
                 bad.append((n, "unused rows", 0))
             mine = mine[:, :ref.shape[1]]
         if float(np.abs(ref).max()) == 0.0:
@@ -110,7 +109,7 @@ def compare_all(tagname, model, grads, ref_grads, report):
             rc = row_check(mine if mine.ndim > 1 else mine[None], ref if ref.ndim > 1 else ref[None])
             if rc > worst["row"]:
                 worst["row"], worst["row_at"] = rc, n
-            if rc > 0.08:
+            if rc > 0.01:
                 bad.append((n, "row", rc))
     report[tagname] = worst
     return bad
@@ -124,32 +123,15 @@ def _dump(report, name):
 
 @pytest.mark.parametrize("tag,extra", MODES)
 def test_bf16_captured_step_gradients_full_cifar_geometry(tag, extra):
-    """d=192, L=6, H=6 (BASELINE configs 2-4), B=16, bf16, default fusions, HIP graph: what bench.py times."""
-    from vitpe.engine import TrainEngine
-    cfg, model = build(tag, extra, {})
-    params = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
-    if tag == "rope-axial":
-        params["pos_embed.inv_freq"] = model.pos_embed.inv_freq.cpu()
-    B = 16
-    images, labels = O.closed_form_batch(cfg, B, salt=3)
-    ref_logits, ref_loss, ref_grads = O.loss_and_grads(cfg, params, images, labels)
-    eng = TrainEngine(model, B, compute_dtype=torch.bfloat16, use_graph=True)
-    assert eng.attn_fused and eng.fuse_ln and eng.fuse_ln_bwd and eng.fuse_mlp and eng.fuse_tail and eng.group_wgrad
-    grads = graph_step_gradients(eng, images.cuda(), labels.cuda())
-    assert eng.graph_fb is not None
-    assert rel_err(eng.logits.cpu(), ref_logits) <= 5e-2
-    assert abs(float(eng.out2[0]) - float(ref_loss)) <= 2e-2
-    report = {}
-    bad = compare_all(tag, model, grads, ref_grads, report)
-    report[tag]["logits"] = rel_err(eng.logits.cpu(), ref_logits)
-    _dump(report, "bench_path_parity.jsonl")
-    assert not bad, bad
+    """d=192, L=6, H=6 (BASELINE configs 2-4), B=16, bf16, default fusions, HIP graph: what bench.py times, on the
+    reference's own initialisation (trunc-normal / kaiming, vit.py:216-233; PE parameters as positional_encoding.py
+    initialises them) with N(0,1) images -- the weights bench.py runs on.
 
-
-@pytest.mark.parametrize("tag,extra", [m for m in MODES if m[0] in ("rope-axial", "relative")])
-def test_bf16_captured_step_gradients_random_init(tag, extra):
-    """Same on the reference's own initialisation (trunc-normal / kaiming, vit.py:216-233) -- the weights bench.py
-    runs on -- with N(0,1) images."""
+    (The closed-form sin() weights of the fp32 fixtures are NOT used here: that model's gradient shrinks by 1e-4 from
+    the head to the patch embedding through cancellation between the residual path and the branches, so any 8-bit
+    activation format reproduces the early layers' gradients to 10-30 % only -- identical figures with every fusion
+    switched off, 2e-5 in fp32: tools/diag_closed_form.py.  The fp32 engine is checked on those weights at the full
+    geometry in test_fp32_engine_full_cifar_geometry_closed_form_weights below.)"""
     from vitpe.engine import TrainEngine
     cfg, model = build(tag, extra, {}, seeded=True)
     params = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
@@ -160,13 +142,34 @@ def test_bf16_captured_step_gradients_random_init(tag, extra):
     images, labels = torch.randn(B, 3, 32, 32, generator=g), torch.randint(0, 10, (B,), generator=g)
     ref_logits, ref_loss, ref_grads = O.loss_and_grads(cfg, params, images, labels)
     eng = TrainEngine(model, B, compute_dtype=torch.bfloat16, use_graph=True)
+    assert eng.attn_fused and eng.fuse_ln and eng.fuse_ln_bwd and eng.fuse_mlp and eng.fuse_tail and eng.group_wgrad
+    assert eng.recompute_ln
     grads = graph_step_gradients(eng, images.cuda(), labels.cuda())
+    assert eng.graph_fb is not None
+    report = {}
+    bad = compare_all(tag, model, grads, ref_grads, report)
+    report[tag]["logits"] = rel_err(eng.logits.cpu(), ref_logits)
+    _dump(report, "bench_path_parity.jsonl")
     assert rel_err(eng.logits.cpu(), ref_logits) <= 5e-2
     assert abs(float(eng.out2[0]) - float(ref_loss)) <= 2e-2
-    report = {}
-    bad = compare_all(tag + "/random-init", model, grads, ref_grads, report)
-    _dump(report, "bench_path_parity.jsonl")
     assert not bad, bad
+
+
+def test_fp32_engine_full_cifar_geometry_closed_form_weights():
+    """fp32 engine (exact-fp32 MFMA, fused attention + LayerNorm fusions) at d=192, L=6 on the closed-form weights of
+    the golden fixtures: logits / loss 1e-4, every gradient 1e-3 against the oracle."""
+    from vitpe.engine import TrainEngine
+    cfg, model = build("rope-mixed", {}, {})
+    params = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+    images, labels = O.closed_form_batch(cfg, 8, salt=3)
+    ref_logits, ref_loss, ref_grads = O.loss_and_grads(cfg, params, images, labels)
+    eng = TrainEngine(model, 8, compute_dtype=torch.float32, use_graph=False)
+    eng._load_batch(images.cuda(), labels.cuda())
+    eng.forward_backward()
+    assert rel_err(eng.logits.cpu(), ref_logits) < 1e-4
+    assert abs(float(eng.out2[0]) - float(ref_loss)) < 1e-4
+    for n, p in model.named_parameters():
+        assert rel_err(p.grad.cpu(), ref_grads[n]) < 1e-3, n
 
 
 IMNET12 = dict(img_size=224, patch_size=16, embed_dim=768, depth=12, num_heads=12)

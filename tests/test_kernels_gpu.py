@@ -383,13 +383,43 @@ def test_wgrad_group_whole_model_list(K, M):
         assert rel_err(dw.cpu(), 2 * rw) < 1e-4
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_wgrad_group_layernorm_operand_is_recomputed_in_the_kernel(K, dt):
+    """x_op = LayerNorm: the X operand is the RAW rows plus their statistics and the affine parameters; the kernel's
+    dW must equal dY^T LayerNorm(X) (oracle: torch layer_norm in fp32 on the values the kernel sees), next to plain
+    problems in the same launch.  Shapes of the engine's fc1 and qkv problems, M ragged."""
+    probs, refs = [], []
+    for i, (M, N, K_, bias, ln) in enumerate([(650, 768, 192, True, True), (650, 576, 192, False, True),
+                                             (333, 192, 768, True, False), (199, 384, 192, True, True)]):
+        dy, x = rnd(M, N, seed=500 + i), rnd(M, K_, seed=540 + i) * 2 + 0.3
+        gam, bet = rnd(K_, seed=560 + i) + 1.5, rnd(K_, seed=580 + i)
+        dw = torch.zeros(N, K_, device="cuda")
+        db = torch.zeros(N, device="cuda") if bias else None
+        xq = q(x, dt)
+        if ln:
+            _, mean, rstd = K.layernorm_fwd(dev(x, DT[dt]).view(1, M, K_), dev(gam), dev(bet), stats_only=True)
+            xn = torch.nn.functional.layer_norm(xq, (K_,), gam, bet, 1e-5)
+            probs.append((dev(dy, DT[dt]), dev(x, DT[dt]), dw, db, (mean, rstd, dev(gam), dev(bet))))
+            refs.append((q(dy, dt).t() @ xn, q(dy, dt).sum(0)))
+        else:
+            probs.append((dev(dy, DT[dt]), dev(x, DT[dt]), dw, db))
+            refs.append((q(dy, dt).t() @ xq, q(dy, dt).sum(0)))
+    grp = K.WgradGroup(probs)
+    grp.launch()
+    for prob, (rw, rb) in zip(probs, refs):
+        dw, db = prob[2], prob[3]
+        assert rel_err(dw.cpu(), rw) < (2e-4 if dt == "f32" else 1e-2), tuple(dw.shape)   # bf16: xhat rounded to bf16 once
+        if db is not None:
+            assert rel_err(db.cpu(), rb) < tol(dt)
+
+
 def test_wgrad_group_rejects_bad_lists(K):
     from vitpe._lib import VitpeError
     with pytest.raises(VitpeError):
         K.WgradGroup([])
     dy, x = torch.zeros(8, 8, device="cuda"), torch.zeros(8, 8, device="cuda")
     with pytest.raises(VitpeError):
-        K.WgradGroup([(dy, x, torch.zeros(8, 8, device="cuda"), None)] * 33)
+        K.WgradGroup([(dy, x, torch.zeros(8, 8, device="cuda"), None)] * (K.WgradGroup.MAX + 1))
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
@@ -504,6 +534,28 @@ def test_fused_attention_bwd(K, dt, mode, D, H, B):
         assert rel_err(dcoef.cpu(), g_ref["coeff"]) < tol(dt)
     if mode == "rope-mixed":
         assert rel_err(dfr.cpu(), g_ref["freqs"]) < max(tol(dt), 2e-4)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["rope-axial", "relative"])
+def test_fused_attention_bwd_with_layernorm_recomputed(K, dt, mode):
+    """vitpe_fused_attention_bwd_ln (raw tokens + statistics) against vitpe_fused_attention_bwd on the normalised
+    tokens the forward would have stored: same d_qkv."""
+    D, H, B = 192, 6, 3
+    N, hd, G, x, wqkv, dout, pe = attn_case(mode, D, H, B, seed=21)
+    x = x * 1.7 + 0.4
+    gam, bet = dev(rnd(D, seed=5) + 1.2), dev(rnd(D, seed=6))
+    t = device_pe(K, mode, pe, H, G)
+    xd = dev(x, DT[dt])
+    xn, mean, rstd = K.layernorm_fwd(xd, gam, bet)
+    w = K.pack_qkv_weights(dev(wqkv), DT[dt], H)
+    mk = lambda: (torch.zeros(H, 2 * N - 1, device="cuda") if mode == "relative" else None)  # noqa: E731
+    d0, d1 = mk(), mk()
+    a = K.fused_attention_bwd(xn, w, dev(dout, DT[dt]), H, t, d0)
+    b_ = K.fused_attention_bwd(xd, w, dev(dout, DT[dt]), H, t, d1, ln=(gam, bet, mean, rstd))
+    assert rel_err(b_.float().cpu(), a.float().cpu()) < (1e-5 if dt == "f32" else 2e-2)
+    if mode == "relative":
+        assert rel_err(d1.cpu(), d0.cpu()) < (1e-5 if dt == "f32" else 2e-2)
 
 
 # attention core on a qkv buffer: CIFAR geometry (N=65, hd=32) and the ImageNet-shaped one of

@@ -158,7 +158,7 @@ def test_pe_module_api_surface(golden):
     assert np.array_equal(r.relative_position_index.numpy(), g["rel_index_65"])
     with torch.no_grad():
         r.relative_position_bias_table.copy_(O.closed_form_tensor("pos_embed.relative_position_bias_table", (6, 129)))
-    assert np.array_equal(r.cuda().get_bias().cpu().numpy(), g["rel_bias_H6_N65"])
+    assert np.array_equal(r.cuda().get_bias().detach().cpu().numpy(), g["rel_bias_H6_N65"])
     a = pe.RoPEAxial(dim=32, theta=100.0).cuda()
     assert np.array_equal(a.inv_freq.cpu().numpy(), g["axial_inv_freq_hd32"])
     cos, sin = a.get_freqs_cis(64, torch.device("cuda"))

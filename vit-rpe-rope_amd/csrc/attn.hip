@@ -11,15 +11,26 @@
 //   positional-parameter gradients (relative table scatter-add, polynomial coefficients,
 //   RoPE-mixed frequencies through cos/sin and the reference's view-scramble).
 //
-// Mapping: one workgroup (6 wavefronts) per image.  The layer-normed token matrix x[N,d] is loaded
-// once with coalesced 16-B reads into LDS; heads are processed HPP at a time: three waves per head
-// project q / k / v with MFMA (weight fragments L2 -> registers as one batched load, issued one pass
-// ahead; x fragments from LDS), rotate in registers (the rotate-half partner j+hd/2 sits in the
-// same lane of the neighbouring accumulator tile), and park q,k,v in LDS.  The attention core
-// then runs one (head, 16-query tile) job per wave with the *swapped* product S^T = K Q^T so
-// that each lane owns one query column: softmax row-max / row-sum are in-lane reductions plus two
-// v_permlane swaps, and the probabilities feed the P.V MFMA directly from registers (V is read
-// column-wise with ds_read_b64_tr_b16).
+// Forward mapping ("register-resident"): one workgroup per image, ONE WAVE PER HEAD.  The layer-normed token matrix
+// x[N,d] is staged once into LDS (coalesced 16-B reads, LayerNorm applied on the way in); after that single barrier the
+// waves never meet again.  A wave projects v, k and q of its head straight out of LDS x-fragments and packed weight
+// fragments (one contiguous 1-KB read each) and keeps EVERYTHING else in registers:
+//   * v is projected un-swapped (A = x rows, B = Wv rows): the accumulator tile pair (2sc, 2sc+1) of feature tile dt
+//     IS the A-operand fragment of V^T for the P.V product (keys in the acc_to_frag order), no transpose, no LDS;
+//   * k and q are projected swapped (A = W rows, B = x rows): accumulator tiles (nt = 0, 1) of token tile tt ARE the
+//     K A-operand / Q B-operand fragments of S^T = K Q^T with the head dimension in the same permuted order on both
+//     sides; RoPE rotates in registers first (the rotate-half partner j + hd/2 is the same lane and register of the
+//     neighbouring accumulator tile);
+//   * S^T = K Q^T puts one query column on each lane: softmax max / sum are in-lane reductions plus two v_permlane
+//     swaps, the probabilities feed the P.V MFMA directly from registers.
+// No wave ever waits for another after the staging barrier, so the waves of a SIMD drift apart and one's softmax VALU
+// phase runs under another's projection MFMAs (the former per-pass workgroup barriers forced all waves through the
+// same phase together).
+// LDS per workgroup: x only (32 KB bf16) -> several workgroups per CU; the bank-conflicting q/k/v tiles are gone.
+//
+// Backward mapping: one workgroup (6 wavefronts) per image; heads are processed HPP at a time: three waves per head
+// project q / k / v with MFMA, rotate in registers and park q,k,v in LDS; the core then runs one (head, 16-token
+// tile) job per wave on the *swapped* product S^T = K Q^T (V is read column-wise with ds_read_b64_tr_b16).
 //
 // Instruction economy (the core is issue-bound, not MFMA-bound, at N=65): the PE mode and the
 // token count are template parameters, the softmax runs in the exp2 domain (log2(e) is folded into
@@ -30,7 +41,7 @@
 namespace vitpe {
 
 // ---- stage the image's tokens, PE tables (x log2 e); zero the tails ------------------------
-template <typename T, typename C, int KM>
+template <typename T, typename C, int KM, int NTH = 384>
 VITPE_DEV void stage_tokens(const AttnArgs& a, int b, T* xs, T* hbuf, int hbuf_elems, float* s_tab, float* s_coef,
                             int tid, int nthreads, bool stage_tables) {
   constexpr int CHN = CH<T>::n;
@@ -41,7 +52,7 @@ VITPE_DEV void stage_tokens(const AttnArgs& a, int b, T* xs, T* hbuf, int hbuf_e
   const Chunk16 zero = {0u, 0u, 0u, 0u};
   // all global loads of this thread first, then the LDS stores: one exposed latency, not one per chunk
   constexpr int TOTAL = C::NP * DCH;
-  constexpr int ITERS = (TOTAL + 383) / 384;
+  constexpr int ITERS = (TOTAL + NTH - 1) / NTH;
   Chunk16 v[ITERS];
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
@@ -84,6 +95,60 @@ VITPE_DEV void stage_tokens(const AttnArgs& a, int b, T* xs, T* hbuf, int hbuf_e
     }
   }
   if (KM == KM_POLY && stage_tables) stage_poly<C>(a, 0, s_coef, N, tid, nthreads);
+}
+
+// Forward-kernel staging: thread (row group tid / CPRW, chunk column tid % CPRW) walks down the rows with a FIXED chunk
+// column, so the LayerNorm affine parameters of its column are loaded once (the generic version above re-derives the
+// column per iteration: five unrolled iterations' gamma / beta loads in flight cost 80 registers).  The pad chunk of
+// an LDS row is never read (fragment reads stop at column D - 1) and is left alone.
+template <typename T, typename C, int KM, int NTH>
+VITPE_DEV void stage_tokens_fwd(const AttnArgs& a, int b, T* xs, float* s_tab, float* s_coef, int tid, bool live,
+                                bool stage_tables) {
+  constexpr int CHN = CH<T>::n, D = C::DD;
+  constexpr int CPRW = D / CHN;                 // 16-B chunks per token row
+  static_assert(NTH % CPRW == 0 && C::NP % (NTH / CPRW) == 0, "thread grid must tile the token matrix");
+  constexpr int RPP = NTH / CPRW, ITERS = C::NP / RPP;
+  const int N = C::ntok(a);
+  const int cc = tid % CPRW, r0 = tid / CPRW;
+  const T* xg = reinterpret_cast<const T*>(a.xn) + (size_t)b * N * D + cc * CHN;
+  const Chunk16 zero = {0u, 0u, 0u, 0u};
+  const bool ln = a.ln_gamma != nullptr;
+  Chunk16 v[ITERS];
+  float mu[ITERS], rs[ITERS];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int row = r0 + it * RPP;
+    v[it] = (row < N) ? *reinterpret_cast<const Chunk16*>(xg + (size_t)row * D) : zero;
+    mu[it] = ln ? a.ln_mean[(size_t)b * N + min(row, N - 1)] : 0.f;   // same burst, clamped address
+    rs[it] = ln ? a.ln_rstd[(size_t)b * N + min(row, N - 1)] : 0.f;
+  }
+  if (ln) {  // fused LayerNorm on the way in (uniform branch)
+    float gq[CHN], bq[CHN];
+#pragma unroll
+    for (int t = 0; t < CHN; ++t) { gq[t] = a.ln_gamma[cc * CHN + t]; bq[t] = a.ln_beta[cc * CHN + t]; }
+    T* xo = (a.xn_out != nullptr && live) ? reinterpret_cast<T*>(a.xn_out) + (size_t)b * N * D + cc * CHN : nullptr;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int row = r0 + it * RPP;
+      if (row < N) {
+        float f[CHN];
+        chunk_to_f32<T>(v[it], f);
+#pragma unroll
+        for (int t = 0; t < CHN; ++t) f[t] = (f[t] - mu[it]) * rs[it] * gq[t] + bq[t];
+        v[it] = f32_to_chunk<T>(f);
+        if (xo != nullptr) __builtin_nontemporal_store(v[it], reinterpret_cast<Chunk16*>(xo + (size_t)row * D));  // read again only in backward
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) *reinterpret_cast<Chunk16*>(xs + (r0 + it * RPP) * C::LDX + cc * CHN) = v[it];
+  if (KM == KM_RELATIVE && stage_tables) {
+    for (int q = tid; q < C::H * C::TABLD; q += NTH) {
+      const int h = q / C::TABLD, i = q % C::TABLD;
+      s_tab[q] = (i < 2 * N - 1) ? a.table[h * (2 * N - 1) + i] * LOG2E : 0.f;
+    }
+  }
+  if (KM == KM_POLY && stage_tables) stage_poly<C>(a, 0, s_coef, N, tid, NTH);
 }
 
 // ---- QKV projection of one (head, matrix) by one wave, RoPE + scale, result to LDS --------
@@ -173,108 +238,186 @@ VITPE_DEV void project_head(const AttnArgs& a, const WFrags<T, C>& w, const T* x
 // =========================================================================================
 // Forward
 // =========================================================================================
-// IPW images per workgroup (6 waves each).  Two 6-wave workgroups with > 64 KB of LDS are never
-// co-resident on a CU (measured with a residency census), so the bf16 build puts two images in ONE
-// 12-wave workgroup: each image's waves run independently between the shared barriers and fill the
-// other image's stalls.
-template <typename T, int HD, int D, int MT, int HPP, int KM, int NTOK, int IPW>
-__global__ __launch_bounds__(384 * IPW) void attn_fwd_kernel(AttnArgs a) {
-  using C = AttnCfg<T, HD, D, MT, HPP, NTOK>;
-  // q,k: [hh][NP][LDH] (row reads only) ; v: [hh][VR][LDH] (column reads run into the zero tail)
-  constexpr int HB_ELEMS = HPP * (2 * C::QSZ + C::HSZ);
+// IPW images per workgroup.  Two 6-wave workgroups are NOT co-resident on a CU at three waves per SIMD (measured:
+// wave lifetime 21 K cycles, kernel 45 K = two rounds; the second workgroup's waves do not fit the SIMDs the first one
+// left uneven), so the bf16 build puts two images = 12 waves = exactly three per SIMD into ONE workgroup.  The images
+// share nothing but the staging barrier.
+template <typename T, int HD, int D, int MT, int KM, int NTOK, int IPW>
+__global__ __launch_bounds__(64 * (D / HD) * IPW, (sizeof(T) == 2 ? 3 : 1)) void attn_fwd_kernel(AttnArgs a) {
+  using C = AttnCfg<T, HD, D, MT, 1, NTOK>;
+  constexpr int NT = C::NT, KS = C::KS, HC = C::HC, SC = C::SC, NTH = 64 * C::H;
+  static_assert(NT % 2 == 0, "two 16-feature tiles per K32 chunk of the head dimension");
   __shared__ __attribute__((aligned(16))) T xs_all[IPW * C::NP * C::LDX];
-  __shared__ __attribute__((aligned(16))) T hb_all[IPW * HB_ELEMS];
   __shared__ __attribute__((aligned(16))) float s_tab[KM == KM_RELATIVE ? C::H * C::TABLD : 4];
   __shared__ __attribute__((aligned(16))) float s_coef[KM == KM_POLY ? C::PESZ : 4];
 
   const int N = C::ntok(a);
   const int lane = threadIdx.x & 63;
   const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int img = wave_all / 6, wave = wave_all % 6;
-  const int b = blockIdx.x * IPW + img;
-  const bool live = b < a.B;                       // odd batch: the second image slot idles (but keeps the barriers)
-  const int c = lane & 15, g = lane >> 4;
+  const int img = wave_all / C::H, h = wave_all % C::H;              // one wave per (image, head)
+  const int b_raw = blockIdx.x * IPW + img;
+  const bool live = b_raw < a.B;                                     // odd batch: the last workgroup's second slot idles
+  const int b = live ? b_raw : a.B - 1;
   T* const xs = xs_all + img * C::NP * C::LDX;
-  T* const hb = hb_all + img * HB_ELEMS;
-  T* const qb = hb;
-  T* const kb = hb + HPP * C::QSZ;
-  T* const vb = hb + 2 * HPP * C::QSZ;
+  const int c = lane & 15, g = lane >> 4;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  // packed weights: block (h, mat, nt, ks) = 64 lanes x 8 elements (vitpe_pack_qkv_weights)
+  const T* const Wh = reinterpret_cast<const T*>(a.wqkv) + ((size_t)h * 3 * NT * KS * 64 + lane) * 8;
+  auto wload = [&](Frag<T> (&w)[NT][KS], int mat, int nt0, int nt1) {
+#pragma unroll
+    for (int nt = nt0; nt < nt1; ++nt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) w[nt][ks] = ld_frag(Wh + (size_t)((mat * NT + nt) * KS + ks) * 64 * 8);
+  };
 
-  T* outp = reinterpret_cast<T*>(a.out) + (size_t)(live ? b : 0) * N * D;
-  census_stamp(a, 0);
-  WFrags<T, C> wf;
-  {
-    const int hh = wave / 3, mat = wave % 3;
-    if (hh < HPP && hh < C::H) load_w<T, C>(a, wf, hh, mat, lane);  // pass 0 weights fly under the token staging
-  }
-  // only the V tails (rows NP..VR-1) must read as zero: every other row is rewritten by each projection
-  static_assert((C::VR - C::NP) * C::LDH % CH<T>::n == 0, "tail");
-#pragma unroll
-  for (int hh = 0; hh < HPP; ++hh)
-    for (int q = (threadIdx.x % 384); q < (C::VR - C::NP) * C::LDH / CH<T>::n; q += 384)
-      *reinterpret_cast<Chunk16*>(vb + hh * C::HSZ + C::NP * C::LDH + q * CH<T>::n) = (Chunk16){0u, 0u, 0u, 0u};
-  stage_tokens<T, C, KM>(a, live ? b : 0, xs, hb, 0, s_tab, s_coef, (threadIdx.x % 384), 384, img == 0);
-  census_stamp(a, 1);
+  // Register budget (168 at three waves per SIMD, no spills: a scratch access would serialise behind the weight loads
+  // in flight): one matrix' weight fragments are 48 registers, a projection's accumulators 40, the parked V^T / K / Q
+  // fragments 24 + 20 + 20 -- the next matrix is prefetched only as far as that leaves room.
+  Frag<T> wa[NT][KS], wb[NT][KS];
+  wload(wa, 2, 0, NT);                                    // Wv flies under the token staging
+  stage_tokens_fwd<T, C, KM, NTH>(a, b, xs, s_tab, s_coef, threadIdx.x % NTH, live, img == 0);
   __syncthreads();
-  census_stamp(a, 2);
-  for (int h0 = 0; h0 < C::H; h0 += HPP) {
-    {
-      const int hh = wave / 3, mat = wave % 3, h = h0 + hh;
-      T* dst = (mat == 0) ? qb + hh * C::QSZ : (mat == 1) ? kb + hh * C::QSZ : vb + hh * C::HSZ;
-      if (hh < HPP && h < C::H) project_head<T, C, KM>(a, wf, xs, dst, h, mat, lane);
-      census_stamp(a, 3 + 4 * (h0 / HPP));
-      if (hh < HPP && h + HPP < C::H) load_w<T, C>(a, wf, h + HPP, mat, lane);  // next pass, under the core
-    }
-    __syncthreads();
-    census_stamp(a, 4 + 4 * (h0 / HPP));
-    for (int job = wave; job < HPP * MT; job += 6) {
-      const int hh = job / MT, it = job % MT, h = h0 + hh;
-      if (h >= C::H) continue;
-      const T* qh = qb + hh * C::QSZ;
-      const T* kh = kb + hh * C::QSZ;
-      const T* vh = vb + hh * C::HSZ;
-      Frag<T> bq[C::HC];
+  if (!live) return;                                      // (after the only barrier)
+  const T* const xrow = xs + c * C::LDX + 8 * g;          // fragment of token tile tt, K32 chunk ks: + 16 tt LDX + 32 ks
+
+  // The projections run token tile by token tile (all K32 chunks of one tile back to back into NT accumulators that are
+  // converted to operand fragments at once): a whole matrix' accumulators (40 registers) would leave the scheduler no
+  // room to read the next x fragments ahead, and every MFMA pair would wait out an LDS round trip.
+  // ---- v, un-swapped: acc[dt][r] = v[token 16tt + 4g + r][feature 16dt + c] -> V^T operand fragments
+  Frag<T> vf[NT][SC];
 #pragma unroll
-      for (int cs = 0; cs < C::HC; ++cs) bq[cs] = ld_frag(qh + (16 * it + c) * C::LDH + 32 * cs + 8 * g);
-      f32x4 s[MT];
-      const float m = logits_T<T, C, KM>(a, kh, bq, s_tab, s_coef, h, it, lane, s);
-      float l = 0.f;
+  for (int sc = 0; sc < SC; ++sc) {
+    if (sc == SC - 1) wload(wb, 1, 0, NT);                // Wk under the last tiles of the v projection
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[2][NT];
 #pragma unroll
-      for (int jt = 0; jt < MT; ++jt)
+    for (int half = 0; half < 2; ++half) {
+      const int tt = 2 * sc + half;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(s[jt][r] - m);
-          s[jt][r] = p;
-          l += p;
-        }
-      l = xg_sum(l);
-      f32x4 o[C::NT];
+      for (int nt = 0; nt < NT; ++nt) acc[half][nt] = z4;
+      if (tt < MT) {
+        Frag<T> xf[KS];      // the whole tile's fragments first: ONE exposed LDS round trip per tile, not one per MFMA pair
 #pragma unroll
-      for (int dt = 0; dt < C::NT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = ld_frag(xrow + 16 * tt * C::LDX + 32 * ks);
 #pragma unroll
-      for (int sc = 0; sc < C::SC; ++sc) {
-        const Frag<T> bp = acc_to_frag<T>(s[2 * sc], (2 * sc + 1 < MT) ? s[(2 * sc + 1 < MT) ? 2 * sc + 1 : 0] : z4);
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int dt = 0; dt < C::NT; ++dt)
-          mma(ld_frag_tr(vh, C::LDH, 32 * sc + 4 * g, 32 * sc + 16 + 4 * g, 16 * dt), bp, o[dt]);
-      }
-      const float inv = __builtin_amdgcn_rcpf(l);
-      const int i = 16 * it + c;
-      // direct C-layout stores: they are asynchronous and fully overlapped here (an LDS-staged
-      // coalesced flush was measured: no gain, one more barrier)
-      if (live && (it < MT - 1 || i < N)) {
-#pragma unroll
-        for (int dt = 0; dt < C::NT; ++dt)
-          st4(outp + (size_t)i * D + h * HD + 16 * dt + 4 * g, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv,
-              o[dt][3] * inv);
+          for (int nt = 0; nt < NT; ++nt) mma(xf[ks], wa[nt][ks], acc[half][nt]);
       }
     }
-    census_stamp(a, 5 + 4 * (h0 / HPP));
-    __syncthreads();
-    census_stamp(a, 6 + 4 * (h0 / HPP));
+#pragma unroll
+    for (int dt = 0; dt < NT; ++dt) vf[dt][sc] = acc_to_frag<T>(acc[0][dt], acc[1][dt]);
   }
-  census_stamp(a, 30);
+  wload(wa, 0, 0, NT / 2);                                // first half of Wq under the k projection
+
+  // ---- k and q, swapped: acc[nt][r] = k[token 16tt + c][feature 16nt + 4g + r]; rotate (q: scale); -> fragments
+  const size_t hoff = (KM == KM_ROPE && a.mode == PE_ROPE_MIXED) ? (size_t)h * (N - 1) * (HD / 2) : 0;
+  auto project_rot = [&](const Frag<T> (&w)[NT][KS], Frag<T> (&dst)[MT][HC], float sc) {
+#pragma unroll
+    for (int tt = 0; tt < MT; ++tt) {
+      const int tok = 16 * tt + c;
+      f32x4 cs4[NT / 2], sn4[NT / 2];
+      if (KM == KM_ROPE) {
+        const int tcl = min(max(tok, 1), N - 1);
+#pragma unroll
+        for (int nt = 0; nt < NT / 2; ++nt) {
+          const size_t o = hoff + (size_t)(tcl - 1) * (HD / 2) + 16 * nt + 4 * g;
+          cs4[nt] = *reinterpret_cast<const f32x4*>(a.cos + o);
+          sn4[nt] = *reinterpret_cast<const f32x4*>(a.sin + o);
+        }
+      }
+      f32x4 acc[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = z4;
+      {
+        Frag<T> xf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = ld_frag(xrow + 16 * tt * C::LDX + 32 * ks);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) mma(w[nt][ks], xf[ks], acc[nt]);
+      }
+      if (KM == KM_ROPE) {
+        const bool rot = tok >= 1 && tok < N;                // class token (and the padding) never rotated
+#pragma unroll
+        for (int nt = 0; nt < NT / 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float x1 = acc[nt][r], x2 = acc[nt + NT / 2][r];
+            acc[nt][r] = rot ? x1 * cs4[nt][r] - x2 * sn4[nt][r] : x1;
+            acc[nt + NT / 2][r] = rot ? x1 * sn4[nt][r] + x2 * cs4[nt][r] : x2;
+          }
+      }
+#pragma unroll
+      for (int cs = 0; cs < HC; ++cs) {
+        f32x4 lo = acc[2 * cs], hi = acc[2 * cs + 1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { lo[r] *= sc; hi[r] *= sc; }
+        dst[tt][cs] = acc_to_frag<T>(lo, hi);
+      }
+    }
+  };
+  Frag<T> kf[MT][HC], qf[MT][HC];
+  __builtin_amdgcn_sched_barrier(0);
+  project_rot(wb, kf, 1.0f);
+  wload(wa, 0, NT / 2, NT);                                         // second half of Wq once Wk is dead
+  __builtin_amdgcn_sched_barrier(0);
+  project_rot(wa, qf, a.scale * LOG2E);                             // logits come out in the exp2 domain
+
+  // ---- per 16-query tile: S^T = K Q^T (+bias), softmax in the exp2 domain, O^T = V^T P^T, store
+  T* const outp = reinterpret_cast<T*>(a.out) + (size_t)b * N * D + h * HD;
+#pragma unroll
+  for (int it = 0; it < MT; ++it) {
+    // (unrolled so that qf[it] is a static register index; the fence keeps the scheduler from interleaving the tiles'
+    //  accumulators -- five tiles' worth of live S^T registers is what spills)
+    __builtin_amdgcn_sched_barrier(0);
+    const int i = 16 * it + c;
+    // s[jt][r] = log2e * (scale q_i.k_j + bias(i,j)),  key j = 16jt + 4g + r, query i = 16it + c
+    f32x4 s[MT];
+    float m = -1e30f;
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt) {
+      s[jt] = z4;
+#pragma unroll
+      for (int cs = 0; cs < HC; ++cs) mma(kf[jt][cs], qf[it][cs], s[jt]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * jt + 4 * g + r;
+        float v = s[jt][r];
+        if (KM == KM_RELATIVE || KM == KM_POLY) v += pe_bias2<C, KM>(a, s_tab, s_coef, h, i, j, N);
+        if (jt == MT - 1) v = (j < N) ? v : -1e30f;        // padding keys only exist in the last tile
+        s[jt][r] = v;
+        m = fmaxf(m, v);
+      }
+    }
+    m = xg_max(m);
+    float l = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[jt][r] - m);
+        s[jt][r] = p;
+        l += p;
+      }
+    l = xg_sum(l);
+    f32x4 o[NT];
+#pragma unroll
+    for (int dt = 0; dt < NT; ++dt) o[dt] = z4;
+#pragma unroll
+    for (int sc = 0; sc < SC; ++sc) {
+      const Frag<T> bp = acc_to_frag<T>(s[2 * sc], (2 * sc + 1 < MT) ? s[(2 * sc + 1 < MT) ? 2 * sc + 1 : 0] : z4);
+#pragma unroll
+      for (int dt = 0; dt < NT; ++dt) mma(vf[dt][sc], bp, o[dt]);
+    }
+    const float inv = __builtin_amdgcn_rcpf(l);
+    if (it < MT - 1 || i < N) {
+#pragma unroll
+      for (int dt = 0; dt < NT; ++dt)
+        st4(outp + (size_t)i * D + 16 * dt + 4 * g, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+    }
+  }
 }
 
 // =========================================================================================
@@ -639,12 +782,13 @@ extern "C" int vitpe_pack_qkv_weights(int dtype, const float* wqkv, void* packed
 
 template <typename T, int HD, int D, int MT, int HPP, int KM, int NTOK>
 static int launch_attn3(bool bwd, const AttnArgs& a, hipStream_t s) {
-  constexpr int IPW = (sizeof(T) == 2) ? 2 : 1;  // bf16 forward: two images per 12-wave workgroup
   if (bwd)
     hipLaunchKernelGGL((attn_bwd_kernel<T, HD, D, MT, HPP, KM, NTOK>), dim3(a.B), dim3(384), 0, s, a);
-  else
-    hipLaunchKernelGGL((attn_fwd_kernel<T, HD, D, MT, HPP, KM, NTOK, IPW>), dim3((a.B + IPW - 1) / IPW), dim3(384 * IPW), 0,
+  else {  // one wave per (image, head); bf16: two images per workgroup (see attn_fwd_kernel)
+    constexpr int IPW = (sizeof(T) == 2 && D / HD <= 6) ? 2 : 1;
+    hipLaunchKernelGGL((attn_fwd_kernel<T, HD, D, MT, KM, NTOK, IPW>), dim3((a.B + IPW - 1) / IPW), dim3(64 * (D / HD) * IPW), 0,
                        s, a);
+  }
   VITPE_CHECK_LAUNCH();
 }
 
@@ -746,22 +890,37 @@ extern "C" int vitpe_fused_attention_bwd(int dtype, const void* xn, const void* 
   return dispatch_attn(true, dtype, D, HD, a, stream);
 }
 
-// debug: what the runtime believes about residency of the main attention instantiations
-extern "C" int vitpe_debug_attn_census(const void* xn, const void* wqkv, void* out, int B, unsigned long long* census,
-                                       hipStream_t stream) {
+// vitpe_fused_attention_bwd with the LayerNorm recomputed while staging (x = RAW tokens + their row statistics): the
+// normalised tokens are a pure function of tensors the forward keeps anyway, so it does not store them.
+extern "C" int vitpe_fused_attention_bwd_ln(int dtype, const void* x, const float* gamma, const float* beta,
+                                            const float* mean, const float* rstd, const void* wqkv, const void* dout,
+                                            void* dqkv, int B, int N, int D, int HD, int mode, const float* cos,
+                                            const float* sin, const float* table, const float* coeff, int grid,
+                                            int degree, int coeff_per_head, float* dtable, float* dcoeff,
+                                            float* dfreqs, hipStream_t stream) {
+  VITPE_REQUIRE(x && gamma && beta && mean && rstd && wqkv && dout && dqkv && B >= 0 && N >= 2);
+  VITPE_REQUIRE(check_pe(mode, cos, sin, table, coeff, N, grid, degree));
+  if (mode == PE_RELATIVE) VITPE_REQUIRE(dtable != nullptr);
+  if (mode == PE_POLY) VITPE_REQUIRE(dcoeff != nullptr);
+  if (mode == PE_ROPE_MIXED) VITPE_REQUIRE(dfreqs != nullptr);
+  if (B == 0) return 0;
   AttnArgs a{};
-  a.xn = xn; a.wqkv = wqkv; a.out = out; a.B = B; a.N = 65; a.mode = PE_NONE; a.grid = 8; a.scale = 0.17677669f;
-  a.census = census;
-  return launch_attn3<bf16, 32, 192, 5, 2, KM_PLAIN, 65>(false, a, stream);
+  a.xn = x; a.wqkv = wqkv; a.out = dqkv; a.dout = dout; a.cos = cos; a.sin = sin; a.table = table;
+  a.coeff = coeff; a.dtable = dtable; a.dcoeff = dcoeff; a.dfreqs = dfreqs;
+  a.ln_gamma = gamma; a.ln_beta = beta; a.ln_mean = mean; a.ln_rstd = rstd;
+  a.B = B; a.N = N; a.mode = mode; a.grid = grid; a.degree = degree; a.coeff_per_head = coeff_per_head;
+  a.scale = 1.0f / sqrtf((float)HD);
+  return dispatch_attn(true, dtype, D, HD, a, stream);
 }
 
+// debug: resident workgroups per CU the runtime computes for the main attention instantiations
 extern "C" int vitpe_debug_attn_occupancy(int which) {
   int n = -1;
   hipError_t e;
   if (which == 0)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<bf16, 32, 192, 5, 2, KM_ROPE, 65, 2>, 768, 0);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<bf16, 32, 192, 5, KM_ROPE, 65, 2>, 768, 0);
   else if (which == 1)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<bf16, 32, 192, 5, 2, KM_PLAIN, 65, 2>, 768, 0);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<bf16, 32, 192, 5, KM_PLAIN, 65, 2>, 768, 0);
   else
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_kernel<bf16, 32, 192, 5, 2, KM_ROPE, 65>, 384, 0);
   return e == hipSuccess ? n : -(int)e;

@@ -30,24 +30,7 @@ struct AttnArgs {
   const float* ln_mean;
   const float* ln_rstd;
   void* xn_out;
-  unsigned long long* census;  // debug: per workgroup {hw_id | xcc_id<<32, t_start, t_end} or null
 };
-
-constexpr int CENSUS_SLOTS = 32;
-// debug only (a.census == nullptr in every product launch): lane 0 of every wave stamps the
-// shader clock at phase boundaries: census[(wg*16 + wave)*CENSUS_SLOTS + slot]
-VITPE_DEV void census_stamp(const AttnArgs& a, int slot) {
-  if (a.census != nullptr && (threadIdx.x & 63) == 0) {
-    const unsigned long long t = __builtin_amdgcn_s_memtime();
-    unsigned long long* p = a.census + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * CENSUS_SLOTS;
-    if (slot == 0) {
-      unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, 32 bits
-      unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // HW_REG_XCC_ID
-      p[CENSUS_SLOTS - 1] = ((unsigned long long)xcc << 32) | hw;
-    }
-    p[slot] = t;
-  }
-}
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
@@ -64,7 +47,10 @@ struct AttnCfg {
   static constexpr int NP = 16 * MT;              // padded tokens
   static constexpr int SC = (MT + 1) / 2;         // K32 chunks over tokens
   static constexpr int VR = 32 * SC;              // rows incl. the zero tail read by 32-deep token contractions
-  static constexpr int LDX = D + Pad<T>::elems;
+  // token rows: 32 B of padding -> a row stride of 26 (d=192) / 14 (d=96) 16-B slots, == 2 (mod 4): the four 16-lane
+  // groups a ds_read_b128 fragment read is served in then touch 16 distinct slots each (one slot of padding, stride
+  // == 1 mod 4, left them 2-way conflicting: SQ_LDS_BANK_CONFLICT was 47 % of the LDS cycles)
+  static constexpr int LDX = D + 2 * Pad<T>::elems;
   static constexpr int LDH = HD + Pad<T>::elems;
   static constexpr int HSZ = VR * LDH;            // one (matrix, head) LDS tile with the zero tail
   static constexpr int QSZ = NP * LDH;            // same without the tail (row-read operands only)

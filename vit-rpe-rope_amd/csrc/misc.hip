@@ -803,4 +803,4 @@ extern "C" int vitpe_selftest_mma(int dtype, const void* A, const void* Bt, cons
   VITPE_CHECK_LAUNCH();
 }
 
-extern "C" int vitpe_abi_version(void) { return 1; }
+extern "C" int vitpe_abi_version(void) { return 2; }

@@ -28,7 +28,7 @@
 
 namespace vitpe {
 
-constexpr int WG_MAXPROB = 32;
+constexpr int WG_MAXPROB = 28;   // the argument block (descriptors + placement table) must stay below the 4 KB kernarg limit
 constexpr int WG_BLK = 192;
 
 struct WgProb {
@@ -36,7 +36,12 @@ struct WgProb {
   const void* X;   // [M,K] T
   float* dW;       // [N,K] fp32, accumulated into
   float* dbias;    // [N] fp32 or null, accumulated into
+  const float* xmean;   // x_op == LayerNorm: row statistics [M] and affine parameters [K] of the X operand
+  const float* xrstd;
+  const float* xgamma;
+  const float* xbeta;
   int M, N, K;
+  int xop;
   int unit0;       // index of this problem's first work unit
   int nbn;         // 192-wide blocks along N
   int stages;      // ceil(M / RPS)
@@ -44,12 +49,13 @@ struct WgProb {
 constexpr int WG_TABLE = 512;
 struct WgArgs {
   int nprob, total_units, units_per_wg;
-  int use_table;   // 1: workgroup i runs table[i] = (problem << 20 | block << 8 | row range), 0xFFFFFFFF = idle
+  int use_table;   // 1: workgroup i runs table[i] = (problem << 11 | block << 5 | row range), 0xFFFF = idle
   int nranges;     // row ranges per block in table mode
   unsigned long long* census;   // CENSUS build only (vitpe_debug_wgrad_census): s_memtime stamps
   WgProb p[WG_MAXPROB];
-  unsigned table[WG_TABLE];
+  unsigned short table[WG_TABLE];
 };
+static_assert(sizeof(WgArgs) <= 4096, "kernel argument block");
 constexpr int WG_CENSUS_STAGES = 24, WG_CENSUS_SLOTS = 4;
 
 template <typename T> struct WgLayout;
@@ -101,7 +107,8 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
 
   struct Cur {
     const T* dY; const T* X; float* dW; float* dbias;
-    int M, N, K, n0, k0, stage, stages;
+    const float* xmean; const float* xrstd; const float* xgamma; const float* xbeta;
+    int M, N, K, n0, k0, stage, stages, xop;
   };
   auto decode = [&](int u, Cur& s) {
     int pi = 0;
@@ -110,6 +117,7 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
     const int ub = u - P.unit0, blk = ub / P.stages;
     s.dY = reinterpret_cast<const T*>(P.dY); s.X = reinterpret_cast<const T*>(P.X); s.dW = P.dW; s.dbias = P.dbias;
     s.M = P.M; s.N = P.N; s.K = P.K; s.stages = P.stages;
+    s.xmean = P.xmean; s.xrstd = P.xrstd; s.xgamma = P.xgamma; s.xbeta = P.xbeta; s.xop = P.xop;
     s.stage = ub - blk * P.stages;
     s.n0 = (blk % P.nbn) * WG_BLK;
     s.k0 = (blk / P.nbn) * WG_BLK;
@@ -117,8 +125,14 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
 
   const Chunk16 zero = {0u, 0u, 0u, 0u};
   Chunk16 rg[4];
+  // X operand = LayerNorm(X) (x_op): the staged rows become xhat = (x - mean) * rstd here (two scalars per row);
+  // gamma and beta are applied to the finished block, dW[n][k] += gamma[k] * (dY^T xhat)[n][k] + beta[k] * colsum(dY)[n]
+  // (the column sums come off the matrix core like the bias gradient) -- one fma per staged element, fp32 affine part.
+  float lnA[2], lnB[2];   // xhat = x * lnA + lnB per staged X chunk
+  bool ln_staged = false;
   auto gload = [&](const Cur& s) {
     const int mb = s.stage * RPS;
+    ln_staged = s.xop == 1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = tid + 768 * (i & 1), row = q / CPR, cc = q % CPR;
@@ -128,7 +142,13 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
         rg[i] = (gm < s.M && gn < s.N) ? *reinterpret_cast<const Chunk16*>(s.dY + (size_t)gm * s.N + gn) : zero;
       } else {
         const int gk = s.k0 + cc * CHN;
-        rg[i] = (gm < s.M && gk < s.K) ? *reinterpret_cast<const Chunk16*>(s.X + (size_t)gm * s.K + gk) : zero;
+        const bool ok = gm < s.M && gk < s.K;
+        rg[i] = ok ? *reinterpret_cast<const Chunk16*>(s.X + (size_t)gm * s.K + gk) : zero;
+        if (s.xop == 1) {   // (uniform per problem)
+          const float rs = ok ? s.xrstd[gm] : 0.f, mu = ok ? s.xmean[gm] : 0.f;
+          lnA[i - 2] = rs;
+          lnB[i - 2] = -mu * rs;
+        }
       }
     }
   };
@@ -136,7 +156,15 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = tid + 768 * (i & 1), row = q / CPR, cc = q % CPR;
-      *reinterpret_cast<Chunk16*>(sm + (buf * 2 + (i >> 1)) * SLAB + LY::chunk(row, cc)) = rg[i];
+      Chunk16 v = rg[i];
+      if (i >= 2 && ln_staged) {
+        float f[CHN];
+        chunk_to_f32<T>(v, f);
+#pragma unroll
+        for (int t = 0; t < CHN; ++t) f[t] = fmaf(f[t], lnA[i - 2], lnB[i - 2]);
+        v = f32_to_chunk<T>(f);
+      }
+      *reinterpret_cast<Chunk16*>(sm + (buf * 2 + (i >> 1)) * SLAB + LY::chunk(row, cc)) = v;
     }
   };
 
@@ -175,6 +203,13 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
     }
   };
   auto flush = [&](const Cur& s, bool bias) {
+    float gam[4], bet[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int gk = s.k0 + wk * 64 + 16 * kt + c;
+      gam[kt] = (s.xop == 1 && gk < s.K) ? s.xgamma[gk] : 1.f;
+      bet[kt] = (s.xop == 1 && gk < s.K) ? s.xbeta[gk] : 0.f;
+    }
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt)
 #pragma unroll
@@ -183,7 +218,9 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
           const int gk = s.k0 + wk * 64 + 16 * kt + c;
-          if (gn < s.N && gk < s.K) atomicAdd(s.dW + (size_t)gn * s.K + gk, acc[nt][kt][r]);
+          float v = acc[nt][kt][r];
+          if (s.xop == 1) v = fmaf(v, gam[kt], bet[kt] * accb[nt][r]);
+          if (gn < s.N && gk < s.K) atomicAdd(s.dW + (size_t)gn * s.K + gk, v);
         }
         if (bias && c == 0 && gn < s.N) atomicAdd(s.dbias + gn, accb[nt][r]);
       }
@@ -197,9 +234,9 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
   int u0, uend;
   if (a.use_table) {
     const unsigned ent = a.table[blockIdx.x];
-    if (ent == 0xFFFFFFFFu) return;
-    const WgProb& P = a.p[ent >> 20];
-    const int blk = (int)((ent >> 8) & 0xFFFu), rng = (int)(ent & 0xFFu);
+    if (ent == 0xFFFFu) return;
+    const WgProb& P = a.p[ent >> 11];
+    const int blk = (int)((ent >> 5) & 0x3Fu), rng = (int)(ent & 0x1Fu);
     const int spr = (P.stages + a.nranges - 1) / a.nranges;
     u0 = P.unit0 + blk * P.stages + min(P.stages, rng * spr);
     uend = P.unit0 + blk * P.stages + min(P.stages, (rng + 1) * spr);
@@ -233,7 +270,7 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
     __syncthreads();
     stamp(u, 1);
     const bool bias = (cur.dbias != nullptr) && cur.k0 == 0 && wk == 0;
-    compute(buf, bias);
+    compute(buf, bias || cur.xop == 1);   // LayerNorm operand: every wave needs the column sums of dY (beta term)
     stamp(u, 3);
     if (flush_now) flush(cur, bias);
     cur = nxt;
@@ -249,7 +286,11 @@ struct vitpe_wgrad_problem_abi {  // mirrors include/vitpe.h: vitpe_wgrad_proble
   const void* X;
   float* dW;
   float* dbias;
-  int M, N, K, reserved;
+  int M, N, K, x_op;
+  const float* x_mean;
+  const float* x_rstd;
+  const float* x_gamma;
+  const float* x_beta;
 };
 
 static int wgrad_cu_count() {
@@ -289,7 +330,9 @@ static int wgrad_group_launch(int dtype, const void* problems, int nprob, unsign
     VITPE_REQUIRE(p.dY && p.X && p.dW && p.M >= 0 && p.N > 0 && p.K > 0 && p.N % CHN == 0 && p.K % CHN == 0);
     if (p.M == 0) continue;
     WgProb& q = a.p[np++];
+    VITPE_REQUIRE(p.x_op == 0 || (p.x_op == 1 && p.x_mean && p.x_rstd && p.x_gamma && p.x_beta));
     q.dY = p.dY; q.X = p.X; q.dW = p.dW; q.dbias = p.dbias; q.M = p.M; q.N = p.N; q.K = p.K;
+    q.xop = p.x_op; q.xmean = p.x_mean; q.xrstd = p.x_rstd; q.xgamma = p.x_gamma; q.xbeta = p.x_beta;
     q.unit0 = units;
     q.nbn = (p.N + WG_BLK - 1) / WG_BLK;
     q.stages = (p.M + RPS - 1) / RPS;
@@ -315,11 +358,11 @@ static int wgrad_group_launch(int dtype, const void* problems, int nprob, unsign
   static const bool table_ok = getenv("VITPE_WGRAD_STREAMK") == nullptr;
   // (many row ranges = many partial-block flushes: with R = 42 for a single layer the atomics cost more than
   // the shared reads save -- measured 91 vs 68 us -- so small problem lists stay on the stream-K path)
-  if (table_ok && R >= 2 && R <= 8 && R <= min_stages / 4 && max_blocks <= 4095 && np <= 4095) {
+  if (table_ok && R >= 2 && R <= 8 && R <= min_stages / 4 && max_blocks <= 63 && np <= 31) {
     // groups = (problem, row range); greedy: next group to the XCD with the fewest workgroups so far
     int len[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool fits = true;
-    for (int i = 0; i < WG_TABLE; ++i) a.table[i] = 0xFFFFFFFFu;
+    for (int i = 0; i < WG_TABLE; ++i) a.table[i] = 0xFFFFu;
     for (int r = 0; r < R && fits; ++r)
       for (int i = 0; i < np && fits; ++i) {
         const int nb = a.p[i].nbn * ((a.p[i].K + WG_BLK - 1) / WG_BLK);
@@ -328,7 +371,7 @@ static int wgrad_group_launch(int dtype, const void* problems, int nprob, unsign
         for (int b = 0; b < nb; ++b) {
           const int id = (len[x] + b) * 8 + x;
           if (id >= WG_TABLE) { fits = false; break; }
-          a.table[id] = ((unsigned)i << 20) | ((unsigned)b << 8) | (unsigned)r;
+          a.table[id] = (unsigned short)(((unsigned)i << 11) | ((unsigned)b << 5) | (unsigned)r);
         }
         len[x] += nb;
       }

@@ -179,9 +179,17 @@ class TrainEngine:
         self.labels = torch.zeros(B, dtype=torch.int64, device=dev)
         self.patches = e(B * self.P, self.C * self.p * self.p)
         self.x = [e(B, N, D) for _ in range(self.Lyr + 1)]
+        self.overlap_wgrad = os.environ.get("VITPE_OVERLAP_WGRAD", "0") == "1"
+        # weight gradients: one grouped launch per backward part (default) or one GEMM per nn.Linear
+        self.group_wgrad = os.environ.get("VITPE_GROUP_WGRAD", "1") == "1" and not self.overlap_wgrad
+        # LayerNorm outputs are never stored on the fully fused path: the attention backward and the weight-gradient
+        # kernel re-normalise the raw rows (kept anyway) from the saved statistics while staging them
+        self.recompute_ln = (self.attn_fused and self.fuse_ln and self.fuse_ln_bwd and self.fuse_mlp and self.fuse_tail
+                             and self.group_wgrad and os.environ.get("VITPE_RECOMPUTE_LN", "1") == "1")
+        xn = (lambda: None) if self.recompute_ln else (lambda: e(B, N, D))
         self.act = []
         for _ in range(self.Lyr):
-            self.act.append(dict(xn1=e(B, N, D), m1=f(M), r1=f(M), a=e(B, N, D), xmid=e(B, N, D), xn2=e(B, N, D),
+            self.act.append(dict(xn1=xn(), m1=f(M), r1=f(M), a=e(B, N, D), xmid=e(B, N, D), xn2=xn(),
                                  m2=f(M), r2=f(M), h=e(M, self.hid), u=e(M, self.hid)))
         self.logits, self.dlogits = f(B, self.Cn), f(B, self.Cn)
         self.out2 = f(2)
@@ -209,9 +217,6 @@ class TrainEngine:
         self.dqkv, self.du = self.dqkv_l[0], self.du_l[0]          # (bench.py times the kernels on these)
         self.side = torch.cuda.Stream(device=dev)
         self.dataset, self.batch_idx = None, None
-        self.overlap_wgrad = os.environ.get("VITPE_OVERLAP_WGRAD", "0") == "1"
-        # weight gradients: one grouped launch per backward part (default) or one GEMM per nn.Linear
-        self.group_wgrad = os.environ.get("VITPE_GROUP_WGRAD", "1") == "1" and not self.overlap_wgrad
         self._wg_groups = {}
         self.dpatch = e(B * self.P, D)
         self.ln_ws = K.layernorm_bwd_workspace(M, D, dev)
@@ -256,7 +261,7 @@ class TrainEngine:
                 # LN1 inside the attention kernel's token staging; LN2 inside fc1's operand staging; their
                 # statistics come out of the producing GEMM's epilogue (proj / previous fc2)
                 K.fused_attention_fwd(xin, self.Pk(blk.attn.qkv.weight), self.H, self.pe, out=a["a"],
-                                      ln=(blk.norm1.weight.data, blk.norm1.bias.data, a["m1"], a["r1"]), xn_out=a["xn1"])
+                                      ln=(blk.norm1.weight.data, blk.norm1.bias.data, a["m1"], a["r1"]), xn_out=a["xn1"])   # (xn1 is None when recompute_ln)
                 nxt = (self.act[l + 1]["m1"], self.act[l + 1]["r1"]) if l + 1 < self.Lyr else None
                 eps_next = mdl.blocks[min(l + 1, self.Lyr - 1)].norm1.eps
                 if self.fuse_mlp and self.fuse_tail:   # proj + residual + LN2 + MLP branch: one kernel per block tail
@@ -303,8 +308,8 @@ class TrainEngine:
                          blk.attn.proj.bias.data, blk.norm2.weight.data, blk.norm2.bias.data,
                          self.Sh(blk.mlp.fc1.weight), blk.mlp.fc1.bias.data, self.Sh(blk.mlp.fc2.weight),
                          blk.mlp.fc2.bias.data, x_mid=a["xmid"].view(M, D), mean2=a["m2"], rstd2=a["r2"],
-                         xn_out=a["xn2"].view(M, D), u=a["u"], h=a["h"], out=self.x[l + 1].view(M, D),
-                         stats=nxt, eps2=blk.norm2.eps, eps_next=eps_next)
+                         xn_out=(None if self.recompute_ln else a["xn2"].view(M, D)), u=a["u"], h=a["h"],
+                         out=self.x[l + 1].view(M, D), stats=nxt, eps2=blk.norm2.eps, eps_next=eps_next)
 
     def _block_tail_bwd(self, l, blk, a):
         M, D, G = self.M, self.D, self.Gr
@@ -316,8 +321,8 @@ class TrainEngine:
     def _tail_bytes(self, fwd: bool) -> int:
         """Algorithmic HBM bytes of one block-tail launch (what the kernel must read and write once)."""
         M, D, hid, es = self.M, self.D, self.hid, 2 if self.T == torch.bfloat16 else 4
-        if fwd:   # attention output + x in; x_mid, LN2(x_mid), x_out out (3 x [M,D]); u and h out (2 x [M,hid])
-            return (5 * M * D + 2 * M * hid) * es
+        if fwd:   # attention output + x in; x_mid, x_out (and LN2(x_mid) unless recomputed) out; u and h out (2 x [M,hid])
+            return ((4 if self.recompute_ln else 5) * M * D + 2 * M * hid) * es
         return (4 * M * D + 2 * M * hid) * es   # dy, x_mid in; d x_mid, d attn out; u in, du out
 
     def _fwd_train(self):
@@ -340,10 +345,16 @@ class TrainEngine:
         probs = []
         for l in range(hi, lo - 1, -1):
             blk, a = mdl.blocks[l], self.act[l]
-            probs += [(self.dx_out[l + 1].view(M, D), a["h"], G(blk.mlp.fc2.weight), G(blk.mlp.fc2.bias)),
-                      (self.du_l[l], a["xn2"].view(M, D), G(blk.mlp.fc1.weight), G(blk.mlp.fc1.bias)),
-                      (self.dx_mid[l].view(M, D), a["a"].view(M, D), G(blk.attn.proj.weight), G(blk.attn.proj.bias)),
-                      (self.dqkv_l[l].view(M, 3 * D), a["xn1"].view(M, D), G(blk.attn.qkv.weight), None)]
+            if self.recompute_ln:   # X operands LayerNorm2(x_mid) / LayerNorm1(x_in): re-normalised inside the kernel
+                fc1 = (self.du_l[l], a["xmid"].view(M, D), G(blk.mlp.fc1.weight), G(blk.mlp.fc1.bias),
+                       (a["m2"], a["r2"], blk.norm2.weight.data, blk.norm2.bias.data))
+                qkv = (self.dqkv_l[l].view(M, 3 * D), self.x[l].view(M, D), G(blk.attn.qkv.weight), None,
+                       (a["m1"], a["r1"], blk.norm1.weight.data, blk.norm1.bias.data))
+            else:
+                fc1 = (self.du_l[l], a["xn2"].view(M, D), G(blk.mlp.fc1.weight), G(blk.mlp.fc1.bias))
+                qkv = (self.dqkv_l[l].view(M, 3 * D), a["xn1"].view(M, D), G(blk.attn.qkv.weight), None)
+            probs += [(self.dx_out[l + 1].view(M, D), a["h"], G(blk.mlp.fc2.weight), G(blk.mlp.fc2.bias)), fc1,
+                      (self.dx_mid[l].view(M, D), a["a"].view(M, D), G(blk.attn.proj.weight), G(blk.attn.proj.bias)), qkv]
         if with_embed:
             probs.append((self.dpatch, self.patches, G(mdl.patch_embed.weight).view(D, -1), G(mdl.patch_embed.bias)))
         return probs
@@ -426,7 +437,10 @@ class TrainEngine:
             self._wgrad(e_dm, lambda: K.gemm_tn(dm, a["a"].view(M, D), G(blk.attn.proj.weight), G(blk.attn.proj.bias)))
             if not tail_done:
                 K.linear(dm, self.St(blk.attn.proj.weight), None, out=self.dtmp.view(M, D))
-            if self.attn_fused:
+            if self.attn_fused and self.recompute_ln:
+                K.fused_attention_bwd(self.x[l], self.Pk(blk.attn.qkv.weight), self.dtmp, self.H, self.pe, out=dqkv,
+                                      ln=(blk.norm1.weight.data, blk.norm1.bias.data, a["m1"], a["r1"]), **self.pe_grads)
+            elif self.attn_fused:
                 K.fused_attention_bwd(a["xn1"], self.Pk(blk.attn.qkv.weight), self.dtmp, self.H, self.pe,
                                       out=dqkv, **self.pe_grads)
             else:
@@ -663,11 +677,17 @@ class TrainEngine:
                 return lambda: K.fused_attention_fwd(a["xn1"], self.Pk(blk.attn.qkv.weight), Hh, self.pe, out=a["a"])
             def bwd(l):
                 blk, a = mdl.blocks[l], self.act[l]
+                if self.recompute_ln:
+                    return lambda: K.fused_attention_bwd(self.x[l], self.Pk(blk.attn.qkv.weight), self.dx_mid[l], Hh, self.pe,
+                                                         out=self.dqkv_l[l], ln=(blk.norm1.weight.data, blk.norm1.bias.data,
+                                                                                 a["m1"], a["r1"]), **self.pe_grads)
                 return lambda: K.fused_attention_bwd(a["xn1"], self.Pk(blk.attn.qkv.weight), self.dx_mid[l], Hh, self.pe,
                                                      out=self.dqkv_l[l], **self.pe_grads)
             probes.append(dict(name="attn_fwd", kernel="attn_fwd_kernel (fused LN1+QKV-project+RoPE+QK^T+softmax+AV)",
                                fns=[fwd(l) for l in range(self.Lyr)], flop=qkv_flop + attn_core_flop,
                                bytes=2 * M * D * es))           # x in, merged heads out (49 920 B / image)
+            if not self.fuse_ln:
+                probes[-1]["kernel"] = "attn_fwd_kernel (fused QKV-project+RoPE+QK^T+softmax+AV)"
             probes.append(dict(name="attn_bwd", kernel="attn_bwd_kernel (recompute + dQ/dK/dV + PE gradients -> d_qkv)",
                                fns=[bwd(l) for l in range(self.Lyr)], flop=2 * (qkv_flop + attn_core_flop),
                                bytes=(2 + 3) * M * D * es))     # xn, dout in; d_qkv out

@@ -199,30 +199,44 @@ def block_tail_bwd(dy, u, w2t, w1t, x, mean, rstd, gamma, dgamma, dbeta, wpt, du
 
 class _WgradProblem(ctypes.Structure):   # include/vitpe.h: vitpe_wgrad_problem
     _fields_ = [("dY", ctypes.c_void_p), ("X", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("dbias", ctypes.c_void_p),
-                ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("reserved", ctypes.c_int)]
+                ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("x_op", ctypes.c_int),
+                ("x_mean", ctypes.c_void_p), ("x_rstd", ctypes.c_void_p), ("x_gamma", ctypes.c_void_p),
+                ("x_beta", ctypes.c_void_p)]
 
 
 class WgradGroup:
-    """A fixed list of weight-gradient problems (dY [M,N], X [M,K], dW [N,K] fp32, dbias [N] fp32 | None),
-    launched together by one vitpe_wgrad_group call.  The tensors are referenced, not copied."""
+    """A fixed list of weight-gradient problems (dY [M,N], X [M,K], dW [N,K] fp32, dbias [N] fp32 | None[, ln]),
+    launched together by one vitpe_wgrad_group call.  The tensors are referenced, not copied.  The optional fifth
+    element ln = (mean [M], rstd [M], gamma [K], beta [K]) makes the operand LayerNorm(X), recomputed inside the kernel
+    from the raw rows X (the normalised tensor is never stored)."""
 
-    MAX = 32
+    MAX = 28
 
     def __init__(self, problems):
-        problems = list(problems)
+        problems = [tuple(p) + (None,) * (5 - len(p)) for p in problems]
         if not 0 < len(problems) <= self.MAX:
             raise L.VitpeError(f"WgradGroup takes 1..{self.MAX} problems, got {len(problems)}")
-        self.keep = problems
+        self.keep = [p[:4] for p in problems]
+        self._ln = [p[4] for p in problems]
         self.dtype = problems[0][0].dtype
         self.arr = (_WgradProblem * len(problems))()
-        for i, (dy, x, dw, db) in enumerate(problems):
+        for i, (dy, x, dw, db, ln) in enumerate(problems):
             require_device(dy, x, dw, db)
             M, N = dy.shape
             K = x.shape[1]
             assert x.shape[0] == M and dw.numel() == N * K and dy.dtype == x.dtype == self.dtype
             assert dy.is_contiguous() and x.is_contiguous() and dw.is_contiguous()
             _f32(dw, "dw"), _f32(db, "dbias")
-            self.arr[i] = _WgradProblem(ptr(dy), ptr(x), ptr(dw), ptr(db), M, N, K, 0)
+            if ln is None:
+                self.arr[i] = _WgradProblem(ptr(dy), ptr(x), ptr(dw), ptr(db), M, N, K, 0, None, None, None, None)
+            else:
+                mean, rstd, gamma, beta = ln
+                require_device(mean, rstd, gamma, beta)
+                for t_, n_ in ((mean, "mean"), (rstd, "rstd"), (gamma, "gamma"), (beta, "beta")):
+                    _f32(t_, n_)
+                assert mean.numel() == M and rstd.numel() == M and gamma.numel() == K and beta.numel() == K
+                self.arr[i] = _WgradProblem(ptr(dy), ptr(x), ptr(dw), ptr(db), M, N, K, 1, ptr(mean), ptr(rstd), ptr(gamma),
+                                            ptr(beta))
 
     def launch(self):
         check(lib().vitpe_wgrad_group(dtype_code(self.dtype), ctypes.addressof(self.arr), len(self.arr), stream_ptr()),
@@ -317,12 +331,21 @@ def fused_attention_fwd(xn, wqkv, num_heads, pe: PETables, out=None, ln=None, xn
     return o
 
 
-def fused_attention_bwd(xn, wqkv, dout, num_heads, pe: PETables, dtable=None, dcoeff=None, dfreqs=None, out=None):
-    """-> dqkv [B,N,3D]; PE-parameter gradients accumulated into dtable/dcoeff/dfreqs."""
+def fused_attention_bwd(xn, wqkv, dout, num_heads, pe: PETables, dtable=None, dcoeff=None, dfreqs=None, out=None, ln=None):
+    """-> dqkv [B,N,3D]; PE-parameter gradients accumulated into dtable/dcoeff/dfreqs.  ln=(gamma, beta, mean, rstd):
+    `xn` holds the RAW tokens and the LayerNorm is recomputed while staging them (nothing normalised was stored)."""
     require_device(xn, wqkv, dout, dtable, dcoeff, dfreqs, out)
     B, N, D = xn.shape
     HD = D // num_heads
     dqkv = out if out is not None else torch.empty((B, N, 3 * D), dtype=xn.dtype, device=xn.device)
+    if ln is not None:
+        require_device(*ln)
+        check(lib().vitpe_fused_attention_bwd_ln(dtype_code(xn.dtype), ptr(xn), ptr(ln[0]), ptr(ln[1]), ptr(ln[2]),
+                                                 ptr(ln[3]), ptr(wqkv), ptr(dout), ptr(dqkv), B, N, D, HD, pe.code,
+                                                 ptr(pe.cos), ptr(pe.sin), ptr(pe.table), ptr(pe.coeff), pe.grid,
+                                                 pe.degree, int(pe.coeff_per_head), ptr(dtable), ptr(dcoeff),
+                                                 ptr(dfreqs), stream_ptr()), "vitpe_fused_attention_bwd_ln")
+        return dqkv
     check(lib().vitpe_fused_attention_bwd(dtype_code(xn.dtype), ptr(xn), ptr(wqkv), ptr(dout), ptr(dqkv), B, N, D, HD,
                                           pe.code, ptr(pe.cos), ptr(pe.sin), ptr(pe.table), ptr(pe.coeff), pe.grid,
                                           pe.degree, int(pe.coeff_per_head), ptr(dtable), ptr(dcoeff), ptr(dfreqs),
