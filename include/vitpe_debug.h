@@ -18,6 +18,11 @@ int vitpe_debug_attn_occupancy(int which);
 /* phase census of the grouped weight-gradient kernel (a separate template instantiation with s_memtime stamps) */
 int vitpe_debug_wgrad_census(int dtype, const vitpe_wgrad_problem* problems, int nprob, unsigned long long* census,
                              vitpe_stream_t stream);
+/* phase census of the fused attention forward (bf16, d=192, N=65, rope-axial; a separate instantiation with stamps):
+ * census[(workgroup * 16 + wave) * 8 + slot] = s_memtime at 0 start, 1 tokens staged, 2 barrier passed, 3 v projected,
+ * 4 k projected, 5 q projected, 6 end                                                                              */
+int vitpe_debug_attn_census(const void* xn, const void* wqkv, void* out, const float* cos, const float* sin,
+                            int B, unsigned long long* census, vitpe_stream_t stream);
 #ifdef __cplusplus
 }
 #endif

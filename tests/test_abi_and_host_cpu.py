@@ -256,3 +256,20 @@ def test_bench_starts_its_own_ranks_and_also_runs_under_the_launcher(launcher):
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     rc, lines, err = _run_bench(["--gpus", "2", "--dry-run"], env_extra={"WORLD_SIZE": "1", "RANK": "0"})
     assert rc != 0 and not lines
+
+
+def test_train_py_refuses_unsupported_geometries_up_front():
+    """Every flag of the reference CLI is kept; combinations the attention kernels are not compiled for are refused by
+    get_args() with the supported set, the others pass."""
+    sys_path = os.path.join(REPO)
+    import sys
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    import train as T
+    for ok in ([], ["--patch_size", "8"], ["--embed_dim", "384"], ["--num_heads", "3"], ["--img_size", "64"],
+               ["--img_size", "224", "--patch_size", "16", "--embed_dim", "768", "--depth", "12", "--num_heads", "12"]):
+        T.get_args(ok)
+    for bad in (["--num_heads", "12"], ["--img_size", "96"], ["--patch_size", "5"],
+                ["--pos_encoding", "polynomial", "--poly_degree", "9"]):
+        with pytest.raises(SystemExit):
+            T.get_args(bad)

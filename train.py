@@ -56,7 +56,36 @@ def get_args(argv=None):
                         help='directory holding the dataset in its binary format (CIFAR-10 binary batches / MNIST idx '
                              'files); it is loaded once into HBM as uint8 (no download: there is no network here)')
     parser.add_argument('--seed', type=int, default=0, help='seed of the per-epoch shuffle')
-    return parser.parse_args(argv)
+    args = parser.parse_args(argv)
+    check_geometry(parser, args)
+    return args
+
+
+def check_geometry(parser, args):
+    """The reference accepts any geometry ATen can run; here the attention kernels are compiled for a fixed set, so an
+    unsupported combination of flags is refused up front with the list of what works (instead of a launch error)."""
+    from vitpe import _lib
+    if args.img_size % args.patch_size or args.embed_dim % args.num_heads:
+        parser.error(f"--img_size {args.img_size} must be a multiple of --patch_size {args.patch_size} and --embed_dim "
+                     f"{args.embed_dim} of --num_heads {args.num_heads}")
+    n_tok = (args.img_size // args.patch_size) ** 2 + 1
+    hd = args.embed_dim // args.num_heads
+    dt = _lib.F32 if args.fp32 else _lib.BF16
+    h = _lib.lib()
+    if not (h.vitpe_fused_attention_supported(dt, n_tok, args.embed_dim, hd) or h.vitpe_attention_core_supported(dt, n_tok, hd)):
+        ok = sorted({n for n in range(2, 300) if h.vitpe_attention_core_supported(dt, n, 32)})
+        spans = []
+        for n in ok:
+            if spans and n == spans[-1][1] + 1:
+                spans[-1][1] = n
+            else:
+                spans.append([n, n])
+        parser.error(f"no attention kernel for {n_tok} tokens (img {args.img_size} / patch {args.patch_size}) with head "
+                     f"dimension {hd} (--embed_dim {args.embed_dim} / --num_heads {args.num_heads}): supported head "
+                     f"dimensions 32 and 64, token counts " + ", ".join(f"{a}-{b}" for a, b in spans) +
+                     " (e.g. 32/8 -> 17, 28/4 -> 50, 32/4 -> 65, 224/16 -> 197, 64/4 -> 257)")
+    if args.pos_encoding == 'polynomial' and not 0 <= args.poly_degree <= 7:
+        parser.error("--poly_degree must be in 0..7 (the attention kernels tabulate the polynomial up to degree 7)")
 
 
 DATASETS = {'mnist': dict(in_chans=1, num_classes=10, train=60000, test=10000),

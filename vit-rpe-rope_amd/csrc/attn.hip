@@ -238,11 +238,14 @@ VITPE_DEV void project_head(const AttnArgs& a, const WFrags<T, C>& w, const T* x
 // =========================================================================================
 // Forward
 // =========================================================================================
+#ifndef VITPE_ATTN_STAGGER
+#define VITPE_ATTN_STAGGER 1
+#endif
 // IPW images per workgroup.  Two 6-wave workgroups are NOT co-resident on a CU at three waves per SIMD (measured:
 // wave lifetime 21 K cycles, kernel 45 K = two rounds; the second workgroup's waves do not fit the SIMDs the first one
 // left uneven), so the bf16 build puts two images = 12 waves = exactly three per SIMD into ONE workgroup.  The images
 // share nothing but the staging barrier.
-template <typename T, int HD, int D, int MT, int KM, int NTOK, int IPW>
+template <typename T, int HD, int D, int MT, int KM, int NTOK, int IPW, bool CENSUS = false>
 __global__ __launch_bounds__(64 * (D / HD) * IPW, (sizeof(T) == 2 ? 3 : 1)) void attn_fwd_kernel(AttnArgs a) {
   using C = AttnCfg<T, HD, D, MT, 1, NTOK>;
   constexpr int NT = C::NT, KS = C::KS, HC = C::HC, SC = C::SC, NTH = 64 * C::H;
@@ -261,6 +264,15 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, (sizeof(T) == 2 ? 3 : 1)) void
   T* const xs = xs_all + img * C::NP * C::LDX;
   const int c = lane & 15, g = lane >> 4;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  // CENSUS (debug instantiation only): lane 0 of every wave stamps the shader clock at the phase boundaries
+  auto stamp = [&](int slot) {
+    if (CENSUS) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (lane == 0) a.census[((size_t)blockIdx.x * 16 + wave_all) * 8 + slot] = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  stamp(0);
   // packed weights: block (h, mat, nt, ks) = 64 lanes x 8 elements (vitpe_pack_qkv_weights)
   const T* const Wh = reinterpret_cast<const T*>(a.wqkv) + ((size_t)h * 3 * NT * KS * 64 + lane) * 8;
   auto wload = [&](Frag<T> (&w)[NT][KS], int mat, int nt0, int nt1) {
@@ -276,8 +288,19 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, (sizeof(T) == 2 ? 3 : 1)) void
   Frag<T> wa[NT][KS], wb[NT][KS];
   wload(wa, 2, 0, NT);                                    // Wv flies under the token staging
   stage_tokens_fwd<T, C, KM, NTH>(a, b, xs, s_tab, s_coef, threadIdx.x % NTH, live, img == 0);
+  stamp(1);
   __syncthreads();
+  stamp(2);
   if (!live) return;                                      // (after the only barrier)
+  // Stagger the waves of a SIMD (waves w, w+4, w+8 share one): the projections are MFMA-bound, the attention core is
+  // VALU-bound, and waves that run the same phase together leave one pipe idle.  Issue priority by wave rank lets the
+  // first wave take the matrix pipe, finish its projections early and run its softmax under the next wave's MFMAs.
+  if (VITPE_ATTN_STAGGER) {
+    const int rank = wave_all >> 2;
+    if (rank == 0) __builtin_amdgcn_s_setprio(3);
+    else if (rank == 1) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(1);
+  }
   const T* const xrow = xs + c * C::LDX + 8 * g;          // fragment of token tile tt, K32 chunk ks: + 16 tt LDX + 32 ks
 
   // The projections run token tile by token tile (all K32 chunks of one tile back to back into NT accumulators that are
@@ -308,6 +331,7 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, (sizeof(T) == 2 ? 3 : 1)) void
 #pragma unroll
     for (int dt = 0; dt < NT; ++dt) vf[dt][sc] = acc_to_frag<T>(acc[0][dt], acc[1][dt]);
   }
+  stamp(3);
   wload(wa, 0, 0, NT / 2);                                // first half of Wq under the k projection
 
   // ---- k and q, swapped: acc[nt][r] = k[token 16tt + c][feature 16nt + 4g + r]; rotate (q: scale); -> fragments
@@ -361,10 +385,13 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, (sizeof(T) == 2 ? 3 : 1)) void
   Frag<T> kf[MT][HC], qf[MT][HC];
   __builtin_amdgcn_sched_barrier(0);
   project_rot(wb, kf, 1.0f);
+  stamp(4);
   wload(wa, 0, NT / 2, NT);                                         // second half of Wq once Wk is dead
   __builtin_amdgcn_sched_barrier(0);
   project_rot(wa, qf, a.scale * LOG2E);                             // logits come out in the exp2 domain
+  stamp(5);
 
+  if (VITPE_ATTN_STAGGER) __builtin_amdgcn_s_setprio(0);   // core: below every projecting wave
   // ---- per 16-query tile: S^T = K Q^T (+bias), softmax in the exp2 domain, O^T = V^T P^T, store
   T* const outp = reinterpret_cast<T*>(a.out) + (size_t)b * N * D + h * HD;
 #pragma unroll
@@ -418,6 +445,7 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, (sizeof(T) == 2 ? 3 : 1)) void
         st4(outp + (size_t)i * D + 16 * dt + 4 * g, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
     }
   }
+  stamp(6);
 }
 
 // =========================================================================================
@@ -911,6 +939,18 @@ extern "C" int vitpe_fused_attention_bwd_ln(int dtype, const void* x, const floa
   a.B = B; a.N = N; a.mode = mode; a.grid = grid; a.degree = degree; a.coeff_per_head = coeff_per_head;
   a.scale = 1.0f / sqrtf((float)HD);
   return dispatch_attn(true, dtype, D, HD, a, stream);
+}
+
+// debug: bf16 d=192 rope-axial forward with phase stamps: census[(wg * 16 + wave) * 8 + slot], slots 0 start,
+// 1 tokens staged, 2 barrier passed, 3 v projected, 4 k, 5 q, 6 end (tools/census_attn.py)
+extern "C" int vitpe_debug_attn_census(const void* xn, const void* wqkv, void* out, const float* cos, const float* sin,
+                                       int B, unsigned long long* census, hipStream_t stream) {
+  VITPE_REQUIRE(xn && wqkv && out && cos && sin && census && B > 0);
+  AttnArgs a{};
+  a.xn = xn; a.wqkv = wqkv; a.out = out; a.cos = cos; a.sin = sin; a.B = B; a.N = 65; a.mode = PE_ROPE_AXIAL; a.grid = 8;
+  a.scale = 0.17677669f; a.census = census;
+  hipLaunchKernelGGL((attn_fwd_kernel<bf16, 32, 192, 5, KM_ROPE, 65, 2, true>), dim3((B + 1) / 2), dim3(768), 0, stream, a);
+  VITPE_CHECK_LAUNCH();
 }
 
 // debug: resident workgroups per CU the runtime computes for the main attention instantiations

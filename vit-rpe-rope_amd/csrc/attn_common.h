@@ -30,6 +30,7 @@ struct AttnArgs {
   const float* ln_mean;
   const float* ln_rstd;
   void* xn_out;
+  unsigned long long* census;  // CENSUS instantiation only (vitpe_debug_attn_census): per-wave s_memtime stamps
 };
 
 constexpr float LOG2E = 1.4426950408889634f;

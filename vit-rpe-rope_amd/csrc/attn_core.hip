@@ -471,9 +471,9 @@ using namespace vitpe;
 
 template <typename T, int HD, int MT>
 static int launch_core(bool bwd, const AttnArgs& a, hipStream_t s) {
-  // forward: one wave per query tile; backward: half as many waves (two rounds) so that the
-  // p/dS accumulators of a key-tile job (2*MT f32x4) stay in registers
-  constexpr int NWF = MT, NWB = (MT > 8) ? (MT + 1) / 2 : MT;
+  // forward: one wave per query tile (two rounds above 13 tiles); backward: half as many waves (two rounds) so that
+  // the p/dS accumulators of a key-tile job (2*MT f32x4) stay in registers
+  constexpr int NWF = (MT > 13) ? (MT + 1) / 2 : MT, NWB = (MT > 8) ? (MT + 1) / 2 : MT;
   const dim3 grid((unsigned)(a.B * a.H));
 #define VITPE_CORE_LAUNCH(KM)                                                                                      \
   do {                                                                                                               \
@@ -491,21 +491,54 @@ static int launch_core(bool bwd, const AttnArgs& a, hipStream_t s) {
   VITPE_CHECK_LAUNCH();
 }
 
+// Instantiated geometries: head dimension 32 / 64 and these token-tile counts MT = ceil(N / 16) -- the square grids the
+// reference CLI can produce from its --img_size / --patch_size flags ((img/patch)^2 + 1 tokens): N = 17 (32/8),
+// 50 (28/4, 224/32), 65 (32/4, 64/8: also the fused path), 145..160 (48/4), 197 (224/16: config 5), 257 (64/4, 32/2).
+// Both LDS tiles of the backward must fit 160 KB: fp32 at hd = 64 stops at 13 tiles.
+template <typename T, int HD, int MT>
+constexpr bool core_fits() {
+  using C = AttnCfg<T, HD, HD, MT, 1, 0>;
+  return 2 * (size_t)C::HSZ * sizeof(T) + 6 * 1024 <= 160 * 1024 && MT <= 17;
+}
+#define VITPE_CORE_MTS(X, T, HD) X(T, HD, 2) X(T, HD, 4) X(T, HD, 5) X(T, HD, 10) X(T, HD, 13) X(T, HD, 17)
+
+template <typename T, int HD>
+static int dispatch_core_t(bool bwd, int MT, const AttnArgs& a, hipStream_t s) {
+#define VITPE_CORE_CASE(T_, HD_, MT_)                                                    \
+  if (MT == MT_) {                                                                       \
+    if constexpr (core_fits<T_, HD_, MT_>()) return launch_core<T_, HD_, MT_>(bwd, a, s); \
+    else return (int)hipErrorNotSupported;                                               \
+  }
+  VITPE_CORE_MTS(VITPE_CORE_CASE, T, HD)
+#undef VITPE_CORE_CASE
+  return (int)hipErrorNotSupported;
+}
+
+template <typename T, int HD>
+static bool core_supported_t(int MT) {
+#define VITPE_CORE_CASE(T_, HD_, MT_) if (MT == MT_) return core_fits<T_, HD_, MT_>();
+  VITPE_CORE_MTS(VITPE_CORE_CASE, T, HD)
+#undef VITPE_CORE_CASE
+  return false;
+}
+
 static int dispatch_core(bool bwd, int dtype, int HD, const AttnArgs& a, hipStream_t s) {
   const int MT = (a.N + 15) / 16;
-  if (dtype == 1) {
-    if (HD == 64 && MT == 13) return launch_core<bf16, 64, 13>(bwd, a, s);
-    if (HD == 32 && MT == 5) return launch_core<bf16, 32, 5>(bwd, a, s);
-  } else if (dtype == 0) {
-    if (HD == 64 && MT == 13) return launch_core<float, 64, 13>(bwd, a, s);
-    if (HD == 32 && MT == 5) return launch_core<float, 32, 5>(bwd, a, s);
-  }
+  if (dtype == 1 && HD == 64) return dispatch_core_t<bf16, 64>(bwd, MT, a, s);
+  if (dtype == 1 && HD == 32) return dispatch_core_t<bf16, 32>(bwd, MT, a, s);
+  if (dtype == 0 && HD == 64) return dispatch_core_t<float, 64>(bwd, MT, a, s);
+  if (dtype == 0 && HD == 32) return dispatch_core_t<float, 32>(bwd, MT, a, s);
   return (int)hipErrorNotSupported;
 }
 
 extern "C" int vitpe_attention_core_supported(int dtype, int N, int HD) {
   const int MT = (N + 15) / 16;
-  return (dtype == 0 || dtype == 1) && N >= 2 && ((HD == 64 && MT == 13) || (HD == 32 && MT == 5));
+  if (N < 2) return 0;
+  if (dtype == 1 && HD == 64) return core_supported_t<bf16, 64>(MT);
+  if (dtype == 1 && HD == 32) return core_supported_t<bf16, 32>(MT);
+  if (dtype == 0 && HD == 64) return core_supported_t<float, 64>(MT);
+  if (dtype == 0 && HD == 32) return core_supported_t<float, 32>(MT);
+  return 0;
 }
 
 static int core_check_pe(int mode, const float* cos, const float* sin, const float* table, const float* coeff, int N,
