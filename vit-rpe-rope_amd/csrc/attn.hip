@@ -37,6 +37,7 @@
 // the q scale and into the staged bias table / coefficients), keys are masked only in the last
 // key tile, and every address is a compile-time offset from a per-lane base.
 #include "attn_common.h"
+#include <type_traits>
 
 namespace vitpe {
 
@@ -101,7 +102,7 @@ VITPE_DEV void stage_tokens(const AttnArgs& a, int b, T* xs, T* hbuf, int hbuf_e
 // column, so the LayerNorm affine parameters of its column are loaded once (the generic version above re-derives the
 // column per iteration: five unrolled iterations' gamma / beta loads in flight cost 80 registers).  The pad chunk of
 // an LDS row is never read (fragment reads stop at column D - 1) and is left alone.
-template <typename T, typename C, int KM, int NTH>
+template <typename T, typename C, int KM, int NTH, bool LNF>
 VITPE_DEV void stage_tokens_fwd(const AttnArgs& a, int b, T* xs, float* s_tab, float* s_coef, int tid, bool live,
                                 bool stage_tables) {
   constexpr int CHN = CH<T>::n, D = C::DD;
@@ -112,17 +113,18 @@ VITPE_DEV void stage_tokens_fwd(const AttnArgs& a, int b, T* xs, float* s_tab, f
   const int cc = tid % CPRW, r0 = tid / CPRW;
   const T* xg = reinterpret_cast<const T*>(a.xn) + (size_t)b * N * D + cc * CHN;
   const Chunk16 zero = {0u, 0u, 0u, 0u};
-  const bool ln = a.ln_gamma != nullptr;
+  constexpr bool ln = LNF;   // (compile-time: a run-time test put a branch around every load of the burst)
   Chunk16 v[ITERS];
   float mu[ITERS], rs[ITERS];
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    const int row = r0 + it * RPP;
-    v[it] = (row < N) ? *reinterpret_cast<const Chunk16*>(xg + (size_t)row * D) : zero;
-    mu[it] = ln ? a.ln_mean[(size_t)b * N + min(row, N - 1)] : 0.f;   // same burst, clamped address
-    rs[it] = ln ? a.ln_rstd[(size_t)b * N + min(row, N - 1)] : 0.f;
+    const int row = r0 + it * RPP, rowc = min(row, N - 1);
+    v[it] = *reinterpret_cast<const Chunk16*>(xg + (size_t)rowc * D);   // clamped address, zeroed below: no branch
+    if (row >= N) v[it] = zero;
+    mu[it] = ln ? a.ln_mean[(size_t)b * N + rowc] : 0.f;                // same burst
+    rs[it] = ln ? a.ln_rstd[(size_t)b * N + rowc] : 0.f;
   }
-  if (ln) {  // fused LayerNorm on the way in (uniform branch)
+  if (ln) {  // fused LayerNorm on the way in
     float gq[CHN], bq[CHN];
 #pragma unroll
     for (int t = 0; t < CHN; ++t) { gq[t] = a.ln_gamma[cc * CHN + t]; bq[t] = a.ln_beta[cc * CHN + t]; }
@@ -238,14 +240,11 @@ VITPE_DEV void project_head(const AttnArgs& a, const WFrags<T, C>& w, const T* x
 // =========================================================================================
 // Forward
 // =========================================================================================
-#ifndef VITPE_ATTN_STAGGER
-#define VITPE_ATTN_STAGGER 1
-#endif
 // IPW images per workgroup.  Two 6-wave workgroups are NOT co-resident on a CU at three waves per SIMD (measured:
 // wave lifetime 21 K cycles, kernel 45 K = two rounds; the second workgroup's waves do not fit the SIMDs the first one
 // left uneven), so the bf16 build puts two images = 12 waves = exactly three per SIMD into ONE workgroup.  The images
 // share nothing but the staging barrier.
-template <typename T, int HD, int D, int MT, int KM, int NTOK, int IPW, bool CENSUS = false>
+template <typename T, int HD, int D, int MT, int KM, int NTOK, int IPW, bool LNF, bool CENSUS = false>
 __global__ __launch_bounds__(64 * (D / HD) * IPW, (sizeof(T) == 2 ? 3 : 1)) void attn_fwd_kernel(AttnArgs a) {
   using C = AttnCfg<T, HD, D, MT, 1, NTOK>;
   constexpr int NT = C::NT, KS = C::KS, HC = C::HC, SC = C::SC, NTH = 64 * C::H;
@@ -253,6 +252,14 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, (sizeof(T) == 2 ? 3 : 1)) void
   __shared__ __attribute__((aligned(16))) T xs_all[IPW * C::NP * C::LDX];
   __shared__ __attribute__((aligned(16))) float s_tab[KM == KM_RELATIVE ? C::H * C::TABLD : 4];
   __shared__ __attribute__((aligned(16))) float s_coef[KM == KM_POLY ? C::PESZ : 4];
+  // cos / sin rows of the patch tokens (rope): [table][token][HD/2 + 8]; the 32-B row padding makes the row stride
+  // 6 slots (== 2 mod 4): the per-lane f32x4 reads are bank-conflict free like the x fragments.  A global read here
+  // would expose an L2 round trip per token tile (measured: 860 cycles per tile for 190 cycles of MFMA).
+  constexpr int CSLD = HD / 2 + 8;
+  constexpr int CSROWS = C::NP;                                      // patch tokens 1 .. N-1 at rows 0 .. N-2
+  constexpr int CSTAB = (KM == KM_ROPE) ? C::H * CSROWS * CSLD : 4;  // worst case: per-head tables (rope-mixed)
+  __shared__ __attribute__((aligned(16))) float s_cos[CSTAB];
+  __shared__ __attribute__((aligned(16))) float s_sin[CSTAB];
 
   const int N = C::ntok(a);
   const int lane = threadIdx.x & 63;
@@ -287,20 +294,28 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, (sizeof(T) == 2 ? 3 : 1)) void
   // fragments 24 + 20 + 20 -- the next matrix is prefetched only as far as that leaves room.
   Frag<T> wa[NT][KS], wb[NT][KS];
   wload(wa, 2, 0, NT);                                    // Wv flies under the token staging
-  stage_tokens_fwd<T, C, KM, NTH>(a, b, xs, s_tab, s_coef, threadIdx.x % NTH, live, img == 0);
+  stage_tokens_fwd<T, C, KM, NTH, LNF>(a, b, xs, s_tab, s_coef, threadIdx.x % NTH, live, IPW == 1 || img == 0);
+  if (KM == KM_ROPE) {   // cos / sin tables -> LDS (axial: one table for all heads; mixed: one per head), indexed by
+    // TOKEN: the class token's row and the padding rows hold the identity rotation (1, 0), so the rotation below needs
+    // no per-element select (vit.py:56-68: the class token is never rotated)
+    const int ntab = (a.mode == PE_ROPE_MIXED) ? C::H : 1, P = N - 1;
+    constexpr int F4 = HD / 8;
+    for (int q = threadIdx.x; q < ntab * CSROWS * F4; q += NTH * IPW) {
+      const int f4 = q % F4, row = (q / F4) % CSROWS, t = q / (F4 * CSROWS);
+      f32x4 cv = {1.f, 1.f, 1.f, 1.f}, sv = {0.f, 0.f, 0.f, 0.f};
+      if (row >= 1 && row < N) {
+        const size_t src = ((size_t)t * P + row - 1) * (HD / 2) + 4 * f4;
+        cv = *reinterpret_cast<const f32x4*>(a.cos + src);
+        sv = *reinterpret_cast<const f32x4*>(a.sin + src);
+      }
+      *reinterpret_cast<f32x4*>(&s_cos[(t * CSROWS + row) * CSLD + 4 * f4]) = cv;
+      *reinterpret_cast<f32x4*>(&s_sin[(t * CSROWS + row) * CSLD + 4 * f4]) = sv;
+    }
+  }
   stamp(1);
   __syncthreads();
   stamp(2);
-  if (!live) return;                                      // (after the only barrier)
-  // Stagger the waves of a SIMD (waves w, w+4, w+8 share one): the projections are MFMA-bound, the attention core is
-  // VALU-bound, and waves that run the same phase together leave one pipe idle.  Issue priority by wave rank lets the
-  // first wave take the matrix pipe, finish its projections early and run its softmax under the next wave's MFMAs.
-  if (VITPE_ATTN_STAGGER) {
-    const int rank = wave_all >> 2;
-    if (rank == 0) __builtin_amdgcn_s_setprio(3);
-    else if (rank == 1) __builtin_amdgcn_s_setprio(2);
-    else __builtin_amdgcn_s_setprio(1);
-  }
+  if (!live) return;                                      // (after the last barrier)
   const T* const xrow = xs + c * C::LDX + 8 * g;          // fragment of token tile tt, K32 chunk ks: + 16 tt LDX + 32 ks
 
   // The projections run token tile by token tile (all K32 chunks of one tile back to back into NT accumulators that are
@@ -322,6 +337,7 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, (sizeof(T) == 2 ? 3 : 1)) void
         Frag<T> xf[KS];      // the whole tile's fragments first: ONE exposed LDS round trip per tile, not one per MFMA pair
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) xf[ks] = ld_frag(xrow + 16 * tt * C::LDX + 32 * ks);
+        __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks each read to just before its MFMA pair)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -335,21 +351,12 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, (sizeof(T) == 2 ? 3 : 1)) void
   wload(wa, 0, 0, NT / 2);                                // first half of Wq under the k projection
 
   // ---- k and q, swapped: acc[nt][r] = k[token 16tt + c][feature 16nt + 4g + r]; rotate (q: scale); -> fragments
-  const size_t hoff = (KM == KM_ROPE && a.mode == PE_ROPE_MIXED) ? (size_t)h * (N - 1) * (HD / 2) : 0;
-  auto project_rot = [&](const Frag<T> (&w)[NT][KS], Frag<T> (&dst)[MT][HC], float sc) {
+  const int cs_off = (KM == KM_ROPE && a.mode == PE_ROPE_MIXED) ? h * CSROWS * CSLD : 0;
+  auto project_rot = [&](const Frag<T> (&w)[NT][KS], Frag<T> (&dst)[MT][HC], float sc, auto scaled) {
 #pragma unroll
     for (int tt = 0; tt < MT; ++tt) {
       const int tok = 16 * tt + c;
       f32x4 cs4[NT / 2], sn4[NT / 2];
-      if (KM == KM_ROPE) {
-        const int tcl = min(max(tok, 1), N - 1);
-#pragma unroll
-        for (int nt = 0; nt < NT / 2; ++nt) {
-          const size_t o = hoff + (size_t)(tcl - 1) * (HD / 2) + 16 * nt + 4 * g;
-          cs4[nt] = *reinterpret_cast<const f32x4*>(a.cos + o);
-          sn4[nt] = *reinterpret_cast<const f32x4*>(a.sin + o);
-        }
-      }
       f32x4 acc[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[nt] = z4;
@@ -357,41 +364,44 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, (sizeof(T) == 2 ? 3 : 1)) void
         Frag<T> xf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) xf[ks] = ld_frag(xrow + 16 * tt * C::LDX + 32 * ks);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) mma(w[nt][ks], xf[ks], acc[nt]);
-      }
-      if (KM == KM_ROPE) {
-        const bool rot = tok >= 1 && tok < N;                // class token (and the padding) never rotated
+        __builtin_amdgcn_sched_barrier(0);
+        if (KM == KM_ROPE) {   // this tile's cos / sin rows: read while the matrix pipe drains (no registers held under the MFMAs)
 #pragma unroll
-        for (int nt = 0; nt < NT / 2; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float x1 = acc[nt][r], x2 = acc[nt + NT / 2][r];
-            acc[nt][r] = rot ? x1 * cs4[nt][r] - x2 * sn4[nt][r] : x1;
-            acc[nt + NT / 2][r] = rot ? x1 * sn4[nt][r] + x2 * cs4[nt][r] : x2;
+          for (int nt = 0; nt < NT / 2; ++nt) {
+            cs4[nt] = *reinterpret_cast<const f32x4*>(&s_cos[cs_off + tok * CSLD + 16 * nt + 4 * g]);
+            sn4[nt] = *reinterpret_cast<const f32x4*>(&s_sin[cs_off + tok * CSLD + 16 * nt + 4 * g]);
           }
+        }
+      }
+      if (KM == KM_ROPE) {   // (f32x4 arithmetic: the compiler emits packed v_pk_mul / v_pk_fma pairs)
+#pragma unroll
+        for (int nt = 0; nt < NT / 2; ++nt) {
+          const f32x4 x1 = acc[nt], x2 = acc[nt + NT / 2];
+          acc[nt] = x1 * cs4[nt] - x2 * sn4[nt];
+          acc[nt + NT / 2] = x1 * sn4[nt] + x2 * cs4[nt];
+        }
       }
 #pragma unroll
       for (int cs = 0; cs < HC; ++cs) {
-        f32x4 lo = acc[2 * cs], hi = acc[2 * cs + 1];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { lo[r] *= sc; hi[r] *= sc; }
-        dst[tt][cs] = acc_to_frag<T>(lo, hi);
+        if constexpr (decltype(scaled)::value) dst[tt][cs] = acc_to_frag<T>(acc[2 * cs] * sc, acc[2 * cs + 1] * sc);
+        else dst[tt][cs] = acc_to_frag<T>(acc[2 * cs], acc[2 * cs + 1]);
       }
     }
   };
   Frag<T> kf[MT][HC], qf[MT][HC];
   __builtin_amdgcn_sched_barrier(0);
-  project_rot(wb, kf, 1.0f);
+  project_rot(wb, kf, 1.0f, std::false_type{});
   stamp(4);
   wload(wa, 0, NT / 2, NT);                                         // second half of Wq once Wk is dead
   __builtin_amdgcn_sched_barrier(0);
-  project_rot(wa, qf, a.scale * LOG2E);                             // logits come out in the exp2 domain
+  project_rot(wa, qf, a.scale * LOG2E, std::true_type{});           // logits come out in the exp2 domain
   stamp(5);
 
-  if (VITPE_ATTN_STAGGER) __builtin_amdgcn_s_setprio(0);   // core: below every projecting wave
   // ---- per 16-query tile: S^T = K Q^T (+bias), softmax in the exp2 domain, O^T = V^T P^T, store
   T* const outp = reinterpret_cast<T*>(a.out) + (size_t)b * N * D + h * HD;
 #pragma unroll
@@ -419,16 +429,19 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, (sizeof(T) == 2 ? 3 : 1)) void
       }
     }
     m = xg_max(m);
-    float l = 0.f;
+    f32x2 l2 = {0.f, 0.f};
+    const f32x4 m4 = {m, m, m, m};
 #pragma unroll
-    for (int jt = 0; jt < MT; ++jt)
+    for (int jt = 0; jt < MT; ++jt) {
+      const f32x4 d = s[jt] - m4;                          // packed subtract, packed row sum below: the issue port is
+      f32x4 p;                                             // what this kernel runs out of, not the pipes
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __builtin_amdgcn_exp2f(s[jt][r] - m);
-        s[jt][r] = p;
-        l += p;
-      }
-    l = xg_sum(l);
+      for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(d[r]);
+      s[jt] = p;
+      l2 += (f32x2){p[0], p[1]};
+      l2 += (f32x2){p[2], p[3]};
+    }
+    float l = xg_sum(l2[0] + l2[1]);
     f32x4 o[NT];
 #pragma unroll
     for (int dt = 0; dt < NT; ++dt) o[dt] = z4;
@@ -439,7 +452,31 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, (sizeof(T) == 2 ? 3 : 1)) void
       for (int dt = 0; dt < NT; ++dt) mma(vf[dt][sc], bp, o[dt]);
     }
     const float inv = __builtin_amdgcn_rcpf(l);
-    if (it < MT - 1 || i < N) {
+    if (sizeof(T) == 2) {
+      // Lane (c, g) holds features 16dt + 4g .. +3 of query c for dt = 0, 1: two 8-B pieces 32 B apart.  One
+      // v_permlane16_swap per dword hands the odd lane group's dt-0 piece to the even group and the even group's dt-1
+      // piece to the odd one: every lane then owns 8 CONTIGUOUS features (16 B) -- half the store instructions, and a
+      // row is written as one 64-B segment per 32 features instead of four 8-B pieces (the C-layout stores were
+      // issue-bound: 16 row segments per instruction).
+#pragma unroll
+      for (int dp = 0; dp < NT; dp += 2) {
+        uint32_t lo[2], hi[2];
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2) {
+          bf16x2 pa, pb;
+          const f32x4 oa = o[dp] * inv, ob = o[dp + 1] * inv;
+          pa[0] = (bf16)oa[2 * w2]; pa[1] = (bf16)oa[2 * w2 + 1];
+          pb[0] = (bf16)ob[2 * w2]; pb[1] = (bf16)ob[2 * w2 + 1];
+          const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, pa), __builtin_bit_cast(uint32_t, pb),
+                                                         false, false);
+          lo[w2] = r[0]; hi[w2] = r[1];
+        }
+        // even g: [own dt, neighbour's dt] = features 16dp + 8(g/2) .. +7 ; odd g: the same of tile dp + 1
+        const int f0 = 16 * (dp + (g & 1)) + 8 * (g >> 1);
+        if (it < MT - 1 || i < N)
+          *reinterpret_cast<Chunk16*>(outp + (size_t)i * D + f0) = (Chunk16){lo[0], lo[1], hi[0], hi[1]};
+      }
+    } else if (it < MT - 1 || i < N) {
 #pragma unroll
       for (int dt = 0; dt < NT; ++dt)
         st4(outp + (size_t)i * D + 16 * dt + 4 * g, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
@@ -814,8 +851,9 @@ static int launch_attn3(bool bwd, const AttnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((attn_bwd_kernel<T, HD, D, MT, HPP, KM, NTOK>), dim3(a.B), dim3(384), 0, s, a);
   else {  // one wave per (image, head); bf16: two images per workgroup (see attn_fwd_kernel)
     constexpr int IPW = (sizeof(T) == 2 && D / HD <= 6) ? 2 : 1;
-    hipLaunchKernelGGL((attn_fwd_kernel<T, HD, D, MT, KM, NTOK, IPW>), dim3((a.B + IPW - 1) / IPW), dim3(64 * (D / HD) * IPW), 0,
-                       s, a);
+    const dim3 grid((a.B + IPW - 1) / IPW), block(64 * (D / HD) * IPW);
+    if (a.ln_gamma != nullptr) hipLaunchKernelGGL((attn_fwd_kernel<T, HD, D, MT, KM, NTOK, IPW, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<T, HD, D, MT, KM, NTOK, IPW, false>), grid, block, 0, s, a);
   }
   VITPE_CHECK_LAUNCH();
 }
@@ -949,7 +987,7 @@ extern "C" int vitpe_debug_attn_census(const void* xn, const void* wqkv, void* o
   AttnArgs a{};
   a.xn = xn; a.wqkv = wqkv; a.out = out; a.cos = cos; a.sin = sin; a.B = B; a.N = 65; a.mode = PE_ROPE_AXIAL; a.grid = 8;
   a.scale = 0.17677669f; a.census = census;
-  hipLaunchKernelGGL((attn_fwd_kernel<bf16, 32, 192, 5, KM_ROPE, 65, 2, true>), dim3((B + 1) / 2), dim3(768), 0, stream, a);
+  hipLaunchKernelGGL((attn_fwd_kernel<bf16, 32, 192, 5, KM_ROPE, 65, 2, false, true>), dim3((B + 1) / 2), dim3(768), 0, stream, a);
   VITPE_CHECK_LAUNCH();
 }
 
@@ -958,9 +996,9 @@ extern "C" int vitpe_debug_attn_occupancy(int which) {
   int n = -1;
   hipError_t e;
   if (which == 0)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<bf16, 32, 192, 5, KM_ROPE, 65, 2>, 768, 0);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<bf16, 32, 192, 5, KM_ROPE, 65, 2, true>, 768, 0);
   else if (which == 1)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<bf16, 32, 192, 5, KM_PLAIN, 65, 2>, 768, 0);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<bf16, 32, 192, 5, KM_PLAIN, 65, 2, true>, 768, 0);
   else
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_kernel<bf16, 32, 192, 5, 2, KM_ROPE, 65>, 384, 0);
   return e == hipSuccess ? n : -(int)e;
