@@ -229,6 +229,17 @@ int vitpe_unfold(int dtype, const float* img, void* patches, int B, int C, int S
 int vitpe_unfold_u8(int dtype, const unsigned char* data, const long long* index, const float* mean,
                     const float* stdv, void* patches, float* img_out, int B, int C, int S, int p,
                     vitpe_stream_t stream);
+/* Fused patch embedding for the small-K geometries (K = C p^2 <= 64, (S/p)^2 <= 64 patches, D <= 256, D % 16 == 0:
+ * vitpe_patch_embed_supported): unfold (from fp32 images `img`, XOR from the resident uint8 dataset `data` + `index` with
+ * ToTensor + Normalize as vitpe_unfold_u8) + Conv2d-as-GEMM + bias + absolute PE rows `ape` [P,D] (nullable) + class
+ * token in row 0 -> tokens [B,P+1,D]; `patches` [B*P,K] (nullable) receives the patch matrix for the weight gradient;
+ * mean / rstd (both or neither) the LayerNorm statistics of every token row (vit.py:113).  One launch instead of
+ * vitpe_unfold + vitpe_gemm_nt(EPI_PATCH) + vitpe_layernorm_fwd.                                                   */
+int vitpe_patch_embed_supported(int dtype, int C, int S, int p, int D);
+int vitpe_patch_embed(int dtype, const float* img, const unsigned char* data, const long long* index,
+                      const float* nmean, const float* nstd, const void* W, const float* bias, const float* cls,
+                      const float* ape, void* tokens, void* patches, float* mean, float* rstd, int B, int C, int S,
+                      int p, int D, float eps, vitpe_stream_t stream);
 /* dcls[d] += sum_b dtok[b,0,d]; dape[p,d] += sum_b dtok[b,1+p,d] (NULL to skip);
  * dpatch [B*P,D] T = patch rows of dtok (input of the patch-embed weight gradient)            */
 int vitpe_embed_bwd(int dtype, const void* dtok, float* dcls, float* dape, void* dpatch, int B,
@@ -283,6 +294,16 @@ int vitpe_head_loss(int dtype, const void* x, const float* gamma, const float* b
                     float* ws_yn, float* ws_dyn, void* dx, float* out2, float* metric_acc, float* scratch,
                     float* dWh, float* dbh, float* dgamma, float* dbeta, int B, int Ntok, int D, int Cn,
                     float eps, float grad_scale, vitpe_stream_t stream);
+
+/* The train step's head: vitpe_head_fwd + vitpe_cross_entropy_ctl + vitpe_head_bwd in one launch pair (classes <= 64,
+ * D <= 768, else hipErrorNotSupported).  ctl as vitpe_cross_entropy_ctl.  dx: ONLY the class rows are written -- the
+ * caller keeps rows 1.. of every image zero (they never change).  per_image: [B,2] work buffer ((loss, correct) per
+ * image, summed in fixed order: no atomics on the totals).  Parameter gradients are accumulated.                  */
+int vitpe_head_step(int dtype, const void* x, const float* gamma, const float* beta, const float* Wh,
+                    const float* bh, const long long* labels, float* logits, float* dlogits, float* ws_xhat,
+                    float* ws_yn, float* ws_dyn, void* dx, float* out2, float* metric_acc, float* per_image,
+                    const float* ctl, float* dWh, float* dbh, float* dgamma, float* dbeta, int B, int Ntok,
+                    int D, int Cn, float eps, vitpe_stream_t stream);
 
 /* ---- optimizer + weight shadows (train.py:116,195) ------------------------------------------
  * hp (device, 16 floats): [0]=lr [1]=beta1 [2]=beta2 [3]=eps [4]=weight_decay [5]=step

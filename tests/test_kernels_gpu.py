@@ -616,8 +616,12 @@ def test_attention_core_matches_fused_kernel(K):
 def test_attention_core_unsupported_shape_is_an_error(K):
     from vitpe._lib import VitpeError
     from vitpe.kernels import PETables
-    with pytest.raises(VitpeError):
-        K.attention_core_fwd(torch.zeros(1, 17, 3 * 64, device="cuda"), 2, PETables("none", 4))
+    assert K.attention_core_supported(torch.bfloat16, 17, 32) and K.attention_core_supported(torch.float32, 257, 64)
+    assert not K.attention_core_supported(torch.bfloat16, 65, 16) and not K.attention_core_supported(torch.bfloat16, 101, 32)
+    with pytest.raises(VitpeError):   # head dimension 16 (e.g. --num_heads 12 at d = 192) has no instantiation
+        K.attention_core_fwd(torch.zeros(1, 17, 3 * 32, device="cuda"), 2, PETables("none", 4))
+    with pytest.raises(VitpeError):   # 101 tokens (7 tiles): not in the compiled set
+        K.attention_core_fwd(torch.zeros(1, 101, 3 * 64, device="cuda"), 2, PETables("none", 10))
 
 
 def test_pack_qkv_weights_layout(K):
@@ -825,3 +829,73 @@ def test_fused_head_loss_equals_the_three_kernels(K, dt, B, N, D, Cn):
     with pytest.raises(VitpeError):
         K.head_loss(x, g, b, z(65, D), z(65), labels, z(B, 65), z(B, 65), ws2, dyn2, dx2, o2, macc, scratch, z(65, D), z(65),
                     gg2, gbt2)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("B,N,D,Cn,nvalid", [(37, 65, 192, 10, 37), (37, 65, 192, 10, 20), (5, 17, 96, 3, 5), (9, 65, 192, 64, 4),
+                                             (6, 197, 768, 10, 6), (6, 65, 384, 10, 6)])
+def test_head_step_equals_the_three_kernels(K, dt, B, N, D, Cn, nvalid):
+    """vitpe_head_step (the train step's head, one launch pair) == vitpe_head_fwd + vitpe_cross_entropy_ctl + vitpe_head_bwd,
+    with the ragged-batch scalars (rows >= n_valid masked) and across replays (the scratch re-arms).  The fused kernel
+    writes only the class rows of dx: the other rows keep what the caller put there (zeros in the engine)."""
+    x = dev(rnd(B, N, D, seed=1), DT[dt])
+    g, b = dev(1 + 0.1 * rnd(D, seed=2)), dev(0.1 * rnd(D, seed=3))
+    wh, bh = dev(rnd(Cn, D, seed=4, scale=0.2)), dev(0.1 * rnd(Cn, seed=5))
+    labels = torch.randint(0, Cn, (B,), generator=torch.Generator().manual_seed(6)).cuda()
+    z = lambda *s: torch.zeros(*s, device="cuda")  # noqa: E731
+    ctl = torch.tensor([1.0 / nvalid, 1.0 / nvalid, float(nvalid), 0.0], device="cuda")
+    lg, ws = K.head_fwd(x, g, b, wh, bh, save=True)
+    out2, dlog = K.cross_entropy_ctl(lg, labels, ctl, dlogits=z(B, Cn))
+    gw, gb, gg, gbt = z(Cn, D), z(Cn), z(D), z(D)
+    dx = K.head_bwd(dlog, wh, g, ws, DT[dt], N, gw, gb, gg, gbt)
+    lg2, dlog2, dx2 = z(B, Cn), z(B, Cn), torch.full((B, N, D), 7.0, device="cuda").to(DT[dt])
+    ws2, dyn2 = (z(B, D), z(B, D), z(B)), z(B, D)
+    o2, macc, scratch = z(2), z(2), z(2 * B)
+    gw2, gb2, gg2, gbt2 = z(Cn, D), z(Cn), z(D), z(D)
+    for rep in range(2):
+        K.head_step(x, g, b, wh, bh, labels, lg2, dlog2, ws2, dyn2, dx2, o2, macc, scratch, ctl, gw2, gb2, gg2, gbt2)
+    assert rel_err(lg2.cpu(), lg.cpu()) < 1e-5 and rel_err(dlog2.cpu(), dlog.cpu()) < 1e-5
+    assert float(dlog2[nvalid:].abs().max()) == 0.0 if nvalid < B else True
+    assert rel_err(dx2[:, 0].float().cpu(), dx[:, 0].float().cpu()) < (1e-5 if dt == "f32" else 1e-2)
+    assert float((dx2[:, 1:].float() - 7.0).abs().max()) == 0.0           # rows 1.. untouched
+    assert abs(float(o2[0]) - float(out2[0])) < 1e-5 and float(o2[1]) == float(out2[1])
+    assert abs(float(macc[0]) - 2 * float(out2[0])) < 2e-5 and float(macc[1]) == 2 * float(out2[1])
+    for a2, a1 in ((gw2, gw), (gb2, gb), (gg2, gg), (gbt2, gbt)):
+        assert rel_err(a2.cpu(), 2 * a1.cpu()) < 1e-5                    # accumulated twice
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("C,S,p,D,ape", [(3, 32, 4, 192, False), (3, 32, 4, 192, True), (1, 32, 4, 96, False), (1, 28, 4, 64, True),
+                                         (3, 32, 8, 256, False)])
+def test_fused_patch_embed_equals_unfold_gemm_layernorm(K, dt, C, S, p, D, ape):
+    """vitpe_patch_embed == vitpe_unfold + vitpe_gemm_nt(EPI_PATCH) + vitpe_layernorm_fwd statistics, from fp32 images and
+    from the resident uint8 dataset; the patch matrix it leaves behind is bit-identical to the unfold kernels'."""
+    B, G = 5, S // p
+    P, Kk = G * G, C * p * p
+    if not K.patch_embed_supported(DT[dt], C, S, p, D):
+        pytest.skip("geometry outside the fused kernel's set")
+    img = dev(rnd(B, C, S, S, seed=1))
+    w = dev(rnd(D, Kk, seed=2, scale=0.3), DT[dt])
+    bias, cls = dev(0.1 * rnd(D, seed=3)), dev(0.2 * rnd(D, seed=4))
+    apet = dev(0.1 * rnd(P, D, seed=5)) if ape else None
+    gam, bet = torch.ones(D, device="cuda"), torch.zeros(D, device="cuda")
+    patches = K.unfold(img, p, DT[dt])
+    ref = K.patch_embed_gemm(patches, w, bias, cls, apet, B, P)
+    _, m_ref, r_ref = K.layernorm_fwd(ref, gam, bet, stats_only=True)
+    mean, rstd = torch.empty(B * (P + 1), device="cuda"), torch.empty(B * (P + 1), device="cuda")
+    pout = torch.empty_like(patches)
+    out = K.patch_embed(w, bias, cls, apet, p, DT[dt], images=img, patches_out=pout, stats=(mean, rstd))
+    assert torch.equal(pout, patches)
+    assert rel_err(out.float().cpu(), ref.float().cpu()) < (1e-5 if dt == "f32" else 1e-2)
+    assert rel_err(mean.cpu(), m_ref.cpu()) < (1e-5 if dt == "f32" else 2e-2) and rel_err(rstd.cpu(), r_ref.cpu()) < (1e-5 if dt == "f32" else 2e-2)
+    # uint8 dataset path
+    g = torch.Generator().manual_seed(7)
+    data = torch.randint(0, 256, (11, C, S, S), generator=g, dtype=torch.uint8).cuda()
+    idx = torch.tensor([3, 0, 10, 7, 7], dtype=torch.int64).cuda()
+    mu, sd = dev(torch.tensor([0.4914, 0.4822, 0.4465][:C])), dev(torch.tensor([0.2023, 0.1994, 0.2010][:C]))
+    p8 = K.unfold_u8(data, idx, mu, sd, p, DT[dt])
+    ref8 = K.patch_embed_gemm(p8, w, bias, cls, apet, B, P)
+    pout8 = torch.empty_like(p8)
+    out8 = K.patch_embed(w, bias, cls, apet, p, DT[dt], data=data, index=idx, mean=mu, std=sd, patches_out=pout8)
+    assert torch.equal(pout8, p8)
+    assert rel_err(out8.float().cpu(), ref8.float().cpu()) < (1e-5 if dt == "f32" else 1e-2)

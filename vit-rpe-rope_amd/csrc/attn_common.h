@@ -51,8 +51,8 @@ struct AttnCfg {
   // token rows: 32 B of padding -> a row stride of 26 (d=192) / 14 (d=96) 16-B slots, == 2 (mod 4): the four 16-lane
   // groups a ds_read_b128 fragment read is served in then touch 16 distinct slots each (one slot of padding, stride
   // == 1 mod 4, left them 2-way conflicting: SQ_LDS_BANK_CONFLICT was 47 % of the LDS cycles)
-  static constexpr int LDX = D + 2 * Pad<T>::elems;
-  static constexpr int LDH = HD + Pad<T>::elems;
+  static constexpr int LDX = D + (sizeof(T) == 2 ? 2 : 1) * Pad<T>::elems;   // (fp32 parity build: one slot, as validated; its LDS is full)
+  static constexpr int LDH = HD + (sizeof(T) == 2 ? 2 : 1) * Pad<T>::elems;   // q/k/v/dO tiles: row stride 6 (hd 32) / 10 (hd 64) slots, == 2 (mod 4): row reads AND ds_read_b64_tr_b16 column reads conflict-free (one slot of padding: both 2-way)
   static constexpr int HSZ = VR * LDH;            // one (matrix, head) LDS tile with the zero tail
   static constexpr int QSZ = NP * LDH;            // same without the tail (row-read operands only)
   static constexpr int TABLD = 2 * NP;

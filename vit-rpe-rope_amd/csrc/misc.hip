@@ -383,6 +383,125 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const T* __restrict__ x,
   }
 }
 
+// The train step's head in ONE launch (+ the parameter-gradient kernel): final LayerNorm of the class row, logits,
+// cross-entropy with the device-side scalars of ce_kernel (ragged batches), accuracy, dlogits and the data gradient
+// through the LayerNorm -- one wave per image, every dependent chain as short as the arithmetic allows:
+//   * lane l holds elements l, l + 64, ... of the class row (KD = ceil(D / 64) registers): coalesced 2-B / 4-B loads;
+//   * the logits of up to 8 classes are reduced TOGETHER (eight independent butterfly sums in flight; the r1 kernel's
+//     class loop ran its ten wave reductions back to back: ~6 K cycles of shuffle latency per image);
+//   * rows 1.. of dx are NOT written: the caller keeps them zero (they never change), only the class row is stored.
+// Batch totals: every wave leaves (loss, correct) of its image in per_image [B,2]; head_bwd_params_kernel, which follows
+// anyway, sums them in fixed order into out2 / metric_acc (deterministic, no atomics).
+template <typename T, int KD>
+__global__ __launch_bounds__(256) void head_step_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ Wh,
+                                                        const float* __restrict__ bh, const long long* __restrict__ labels,
+                                                        float* __restrict__ logits, float* __restrict__ dlogits,
+                                                        float* __restrict__ ws_xhat, float* __restrict__ ws_yn,
+                                                        float* __restrict__ ws_dyn, T* __restrict__ dx,
+                                                        float* __restrict__ per_image, const float* __restrict__ ctl,
+                                                        int B, int Ntok, int D, int Cn, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  const float invD = 1.0f / (float)D;
+  const float gscale = ctl[0], lscale = ctl[1];
+  const int nvalid = min(B, (int)ctl[2]);
+  const T* row = x + (size_t)b * Ntok * D;
+  float xv[KD], gam[KD], bet[KD];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < KD; ++k) {
+    const int d = lane + 64 * k;
+    const bool ok = d < D;
+    xv[k] = ok ? to_f32(row[d]) : 0.f;
+    gam[k] = ok ? gamma[d] : 0.f;
+    bet[k] = ok ? beta[d] : 0.f;
+    s += xv[k];
+  }
+  const float mean = wave_sum(s) * invD;
+  float s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < KD; ++k) { const float t = (lane + 64 * k < D) ? xv[k] - mean : 0.f; s2 += t * t; }
+  const float rstd = 1.0f / sqrtf(wave_sum(s2) * invD + eps);
+  float xh[KD], yn[KD];
+#pragma unroll
+  for (int k = 0; k < KD; ++k) {
+    const int d = lane + 64 * k;
+    xh[k] = (d < D) ? (xv[k] - mean) * rstd : 0.f;
+    yn[k] = xh[k] * gam[k] + bet[k];
+    if (d < D) { ws_xhat[(size_t)b * D + d] = xh[k]; ws_yn[(size_t)b * D + d] = yn[k]; }
+  }
+  float z = -3.0e38f;   // lane c < Cn holds logit c
+  for (int c0 = 0; c0 < Cn; c0 += 8) {
+    float part[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      part[j] = 0.f;
+      const int cI = min(c0 + j, Cn - 1);
+#pragma unroll
+      for (int k = 0; k < KD; ++k) {
+        const int d = lane + 64 * k;
+        part[j] += (d < D) ? yn[k] * Wh[(size_t)cI * D + d] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part[j] += __shfl_xor(part[j], o, 64);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (lane == c0 + j && c0 + j < Cn) z = part[j] + bh[c0 + j];
+  }
+  if (lane < Cn) logits[(size_t)b * Cn + lane] = z;
+  float m = z;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  int am = (lane < Cn && z == m) ? lane : 1 << 20;   // first index of the maximum (torch.max semantics)
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) am = min(am, __shfl_xor(am, o, 64));
+  const float e = lane < Cn ? expf(z - m) : 0.f;
+  const float se = wave_sum(e);
+  const int y = (int)labels[b];
+  const float zy = __shfl(z, y, 64);
+  const bool valid = b < nvalid;
+  const float dl = (lane < Cn && valid) ? (e * (1.0f / se) - (lane == y ? 1.f : 0.f)) * gscale : 0.f;
+  if (lane < Cn) dlogits[(size_t)b * Cn + lane] = dl;
+  // data gradient: dyn = dlogits @ Wh, then the LayerNorm backward of the class row
+  float dyn[KD];
+#pragma unroll
+  for (int k = 0; k < KD; ++k) dyn[k] = 0.f;
+  for (int c = 0; c < Cn; ++c) {
+    const float dc = __shfl(dl, c, 64);
+#pragma unroll
+    for (int k = 0; k < KD; ++k) {
+      const int d = lane + 64 * k;
+      dyn[k] += (d < D) ? dc * Wh[(size_t)c * D + d] : 0.f;
+    }
+  }
+  float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < KD; ++k) {
+    const int d = lane + 64 * k;
+    if (d < D) ws_dyn[(size_t)b * D + d] = dyn[k];
+    const float gv = dyn[k] * gam[k];
+    t1 += gv;
+    t2 += gv * xh[k];
+  }
+  t1 = wave_sum(t1) * invD;
+  t2 = wave_sum(t2) * invD;
+  T* drow = dx + (size_t)b * Ntok * D;
+#pragma unroll
+  for (int k = 0; k < KD; ++k) {
+    const int d = lane + 64 * k;
+    if (d < D) drow[d] = from_f32<T>(rstd * (dyn[k] * gam[k] - t1 - xh[k] * t2));
+  }
+  if (lane == 0) {   // per-image results; head_bwd_params_kernel sums them (no same-address atomics: ~12 ns each, serialised)
+    per_image[2 * b] = valid ? ((m + logf(se)) - zy) * lscale : 0.f;
+    per_image[2 * b + 1] = (valid && am == y) ? 1.f : 0.f;
+  }
+}
+
 // head backward, stage 1 (one wave per image): dyn = dlogits @ Wh ; LN backward of the class row;
 // dx row 0 written, rows 1.. zeroed.  ws_dyn [B,D] kept for stage 2.
 template <typename T>
@@ -422,10 +541,28 @@ __global__ __launch_bounds__(256) void head_bwd_rows_kernel(const float* __restr
 // stage 2: column sums over the batch, split over batch chunks (blockIdx.y) + fp32 atomics.
 //   dWh[k][d] += sum_b dlogits[b][k]*yn[b][d] ; dbh[k] += sum_b dlogits[b][k]
 //   dgamma[d] += sum_b dyn*xhat ; dbeta[d] += sum_b dyn
+// per_image (nullable, with out2 / metric_acc): [B,2] (loss, correct) of vitpe_head_step's images, summed in fixed
+// order by workgroup (0,0) into out2 and added to metric_acc.
 __global__ void head_bwd_params_kernel(const float* __restrict__ dlogits, const float* __restrict__ ws_yn,
                                        const float* __restrict__ ws_dyn, const float* __restrict__ ws_xhat,
                                        float* dWh, float* dbh, float* dgamma, float* dbeta, int B, int D, int Cn,
-                                       int bchunk) {
+                                       int bchunk, const float* __restrict__ per_image, float* out2, float* metric_acc) {
+  if (per_image != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {
+    __shared__ float sl[256], sc[256];
+    float l = 0.f, cr = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) { l += per_image[2 * b]; cr += per_image[2 * b + 1]; }
+    sl[threadIdx.x] = l;
+    sc[threadIdx.x] = cr;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+      if (threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      out2[0] = sl[0]; out2[1] = sc[0];
+      if (metric_acc != nullptr) { metric_acc[0] += sl[0]; metric_acc[1] += sc[0]; }
+    }
+  }
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
   const int nW = Cn * D;
@@ -476,6 +613,8 @@ __global__ void embed_bwd_kernel(const T* __restrict__ dtok, float* dcls, float*
 // Fused AdamW over the flat fp32 parameter / gradient / moment buffers (train.py:195:
 // one param group, decoupled weight decay on everything) + bf16 weight shadow + grad reset.
 // hp (device): [0]=lr [1]=beta1 [2]=beta2 [3]=eps [4]=weight_decay [5]=step [6]=bc1 [7]=bc2 [8]=grad_scale
+// (The step counter keeps its own one-thread launch: an in-kernel "last workgroup advances it" variant needs one
+//  same-address arrival atomic per workgroup, ~12 ns each and serialised -- 4096 workgroups made the update 55 us.)
 __global__ void adamw_tick_kernel(float* hp) {
   const float step = hp[5] + 1.0f;
   hp[5] = step;
@@ -714,7 +853,7 @@ extern "C" int vitpe_head_bwd(int dtype, const float* dlogits, const float* Wh, 
   int e = (int)hipGetLastError();
   if (e) return e;
   hipLaunchKernelGGL(head_bwd_params_kernel, dim3((Cn * D + Cn + D + 255) / 256, (B + 31) / 32), dim3(256), 0, st,
-                     dlogits, ws_yn, ws_dyn, ws_xhat, dWh, dbh, dgamma, dbeta, B, D, Cn, 32);
+                     dlogits, ws_yn, ws_dyn, ws_xhat, dWh, dbh, dgamma, dbeta, B, D, Cn, 32, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
   VITPE_CHECK_LAUNCH();
 }
 extern "C" int vitpe_head_loss(int dtype, const void* x, const float* gamma, const float* beta, const float* Wh,
@@ -738,7 +877,44 @@ extern "C" int vitpe_head_loss(int dtype, const void* x, const float* gamma, con
   int e = (int)hipGetLastError();
   if (e) return e;
   hipLaunchKernelGGL(head_bwd_params_kernel, dim3((Cn * D + Cn + D + 255) / 256, (B + 31) / 32), dim3(256), 0, st,
-                     dlogits, ws_yn, ws_dyn, ws_xhat, dWh, dbh, dgamma, dbeta, B, D, Cn, 32);
+                     dlogits, ws_yn, ws_dyn, ws_xhat, dWh, dbh, dgamma, dbeta, B, D, Cn, 32, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+  VITPE_CHECK_LAUNCH();
+}
+template <typename T>
+static int head_step_launch(const T* x, const float* gamma, const float* beta, const float* Wh, const float* bh,
+                            const long long* labels, float* logits, float* dlogits, float* ws_xhat, float* ws_yn,
+                            float* ws_dyn, T* dx, float* per_image, const float* ctl, int B, int Ntok, int D, int Cn,
+                            float eps, hipStream_t st) {
+  const dim3 grid((B + 3) / 4), block(256);
+#define VITPE_HEAD_STEP(KD)                                                                                              \
+  hipLaunchKernelGGL((head_step_kernel<T, KD>), grid, block, 0, st, x, gamma, beta, Wh, bh, labels, logits, dlogits,    \
+                     ws_xhat, ws_yn, ws_dyn, dx, per_image, ctl, B, Ntok, D, Cn, eps)
+  const int kd = (D + 63) / 64;
+  if (kd <= 2) VITPE_HEAD_STEP(2);
+  else if (kd == 3) VITPE_HEAD_STEP(3);
+  else if (kd <= 6) VITPE_HEAD_STEP(6);
+  else if (kd <= 12) VITPE_HEAD_STEP(12);
+  else return (int)hipErrorNotSupported;
+#undef VITPE_HEAD_STEP
+  return (int)hipGetLastError();
+}
+extern "C" int vitpe_head_step(int dtype, const void* x, const float* gamma, const float* beta, const float* Wh,
+                               const float* bh, const long long* labels, float* logits, float* dlogits, float* ws_xhat,
+                               float* ws_yn, float* ws_dyn, void* dx, float* out2, float* metric_acc, float* per_image,
+                               const float* ctl, float* dWh, float* dbh, float* dgamma, float* dbeta, int B, int Ntok,
+                               int D, int Cn, float eps, hipStream_t st) {
+  VITPE_REQUIRE(x && gamma && beta && Wh && bh && labels && logits && dlogits && ws_xhat && ws_yn && ws_dyn && dx && out2 &&
+                per_image && ctl && dWh && dbh && dgamma && dbeta && B >= 0 && (dtype == 0 || dtype == 1));
+  if (Cn < 1 || Cn > 64 || D > 768) return (int)hipErrorNotSupported;
+  if (B == 0) return 0;
+  int e = dtype == 1 ? head_step_launch<bf16>((const bf16*)x, gamma, beta, Wh, bh, labels, logits, dlogits, ws_xhat, ws_yn,
+                                              ws_dyn, (bf16*)dx, per_image, ctl, B, Ntok, D, Cn, eps, st)
+                     : head_step_launch<float>((const float*)x, gamma, beta, Wh, bh, labels, logits, dlogits, ws_xhat, ws_yn,
+                                               ws_dyn, (float*)dx, per_image, ctl, B, Ntok, D, Cn, eps, st);
+  if (e) return e;
+  hipLaunchKernelGGL(head_bwd_params_kernel, dim3((Cn * D + Cn + D + 255) / 256, (B + 31) / 32), dim3(256), 0, st,
+                     dlogits, ws_yn, ws_dyn, ws_xhat, dWh, dbh, dgamma, dbeta, B, D, Cn, 32, (const float*)per_image, out2,
+                     metric_acc);
   VITPE_CHECK_LAUNCH();
 }
 extern "C" int vitpe_embed_bwd(int dtype, const void* dtok, float* dcls, float* dape, void* dpatch, int B, int Ntok,

@@ -117,7 +117,8 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
     const int ub = u - P.unit0, blk = ub / P.stages;
     s.dY = reinterpret_cast<const T*>(P.dY); s.X = reinterpret_cast<const T*>(P.X); s.dW = P.dW; s.dbias = P.dbias;
     s.M = P.M; s.N = P.N; s.K = P.K; s.stages = P.stages;
-    s.xmean = P.xmean; s.xrstd = P.xrstd; s.xgamma = P.xgamma; s.xbeta = P.xbeta; s.xop = P.xop;
+    s.xmean = P.xop ? P.xmean : P.dW; s.xrstd = P.xop ? P.xrstd : P.dW;
+    s.xgamma = P.xgamma; s.xbeta = P.xbeta; s.xop = P.xop;
     s.stage = ub - blk * P.stages;
     s.n0 = (blk % P.nbn) * WG_BLK;
     s.k0 = (blk / P.nbn) * WG_BLK;
@@ -144,11 +145,12 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
         const int gk = s.k0 + cc * CHN;
         const bool ok = gm < s.M && gk < s.K;
         rg[i] = ok ? *reinterpret_cast<const Chunk16*>(s.X + (size_t)gm * s.K + gk) : zero;
-        if (s.xop == 1) {   // (uniform per problem)
-          const float rs = ok ? s.xrstd[gm] : 0.f, mu = ok ? s.xmean[gm] : 0.f;
-          lnA[i - 2] = rs;
-          lnB[i - 2] = -mu * rs;
-        }
+        // row statistics: UNCONDITIONAL loads (plain problems read a dummy word of their own dW): a branch around them
+        // made the compiler drain the whole prefetch (vmcnt(0)) before it, i.e. every stage waited out its HBM latency
+        // (only LOADED here, like the chunks: consuming them now would wait for every load of the burst)
+        const int gs = (s.xop == 1) ? min(gm, s.M - 1) : 0;
+        lnA[i - 2] = s.xrstd[gs];
+        lnB[i - 2] = s.xmean[gs];
       }
     }
   };
@@ -160,8 +162,10 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
       if (i >= 2 && ln_staged) {
         float f[CHN];
         chunk_to_f32<T>(v, f);
+        // (rows past M become -mean * rstd instead of 0: harmless, their dY rows are zero)
+        const float rs = lnA[i - 2], nb = -lnB[i - 2] * rs;
 #pragma unroll
-        for (int t = 0; t < CHN; ++t) f[t] = fmaf(f[t], lnA[i - 2], lnB[i - 2]);
+        for (int t = 0; t < CHN; ++t) f[t] = fmaf(f[t], rs, nb);
         v = f32_to_chunk<T>(f);
       }
       *reinterpret_cast<Chunk16*>(sm + (buf * 2 + (i >> 1)) * SLAB + LY::chunk(row, cc)) = v;

@@ -59,10 +59,14 @@ class TrainEngine:
         self.D, self.H, self.Lyr = m.embed_dim, m.num_heads, len(m.blocks)
         self.p = m.patch_size
         self.C = m.patch_embed.weight.shape[1]
+
         self.P = m.num_patches
         self.N = self.P + 1
         self.grid = int(math.sqrt(self.P))
         self.S = self.grid * self.p
+        # unfold + patch GEMM + bias + APE + class token + first LayerNorm statistics in one kernel (small-K geometries)
+        self.fuse_embed = (os.environ.get("VITPE_FUSE_EMBED", "1") == "1" and
+                           K.patch_embed_supported(compute_dtype, self.C, self.S, self.p, self.D))
         self.hid = m.blocks[0].mlp.fc1.weight.shape[0]
         self.Cn = m.num_classes
         self.M = self.B * self.N
@@ -199,10 +203,10 @@ class TrainEngine:
         self.ce_ctl = torch.zeros(4, dtype=torch.float32, device=dev)
         self._valid = None
         self.set_valid(B)
-        self.head_scratch = torch.zeros(4, dtype=torch.float32, device=dev)
-        # one-launch head + CE + head backward (vitpe_head_loss): measured 45 us against 40 us for the three small
-        # kernels it replaces (one wave per image is a long serial chain) -- off unless VITPE_FUSE_HEAD=1
-        self.fuse_head = self.Cn <= 64 and os.environ.get("VITPE_FUSE_HEAD", "0") == "1"
+        self.head_scratch = torch.zeros(2 * B, dtype=torch.float32, device=dev)   # (loss, correct) per image
+        # one-launch head + CE + head backward (vitpe_head_step; r1's vitpe_head_loss was 45 us against 40 us for the
+        # three small kernels: its class loop serialised ten wave reductions per image).  VITPE_FUSE_HEAD=0: three kernels.
+        self.fuse_head = self.Cn <= 64 and self.D <= 768 and os.environ.get("VITPE_FUSE_HEAD", "1") == "1"
         self.head_ws = (f(B, D), f(B, D), f(B))
         self.ws_dyn = f(B, D)
         # Gradient tensors read by the weight-gradient GEMMs get per-layer buffers (dy = d x_out, dmid = d x_mid,
@@ -210,6 +214,7 @@ class TrainEngine:
         # overwrites anything they may still be reading (288 GB of HBM: ~0.7 GB extra is free)
         self.dtmp = e(B, N, D)
         self.dx_out = [e(B, N, D) for _ in range(self.Lyr + 1)]   # [l] = gradient w.r.t. x[l]
+        self.dx_out[self.Lyr].zero_()   # only its class rows are ever written (head): rows 1.. stay zero
         self.dx_mid = [e(B, N, D) for _ in range(self.Lyr)]
         self.du_l = [e(M, self.hid) for _ in range(self.Lyr)]
         self.dqkv_l = [e(B, N, 3 * D) for _ in range(self.Lyr)]
@@ -241,20 +246,28 @@ class TrainEngine:
     # ---------------------------------------------------------------- forward / backward
     def _forward(self, head=True):
         mdl, B, N, D, M = self.model, self.B, self.N, self.D, self.M
-        if self.dataset is not None:   # resident uint8 dataset: gather + ToTensor + Normalize inside the unfold
-            K.unfold_u8(self.dataset.images, self.batch_idx, self.dataset.mean, self.dataset.std, self.p, self.T,
-                        out=self.patches)
-        else:
-            K.unfold(self.images, self.p, self.T, out=self.patches)
         ape = mdl.pos_embed.pos_embed.data[0, :self.P] if isinstance(mdl.pos_embed, AbsolutePositionalEncoding) else None
-        K.patch_embed_gemm(self.patches, self.Sh(mdl.patch_embed.weight).view(D, -1), mdl.patch_embed.bias.data,
-                           mdl.cls_token.data.view(-1), ape, B, self.P, out=self.x[0])
+        if self.fuse_embed:   # unfold + patch GEMM + bias + APE + class token + block 0's norm1 statistics: one kernel
+            src = (dict(data=self.dataset.images, index=self.batch_idx, mean=self.dataset.mean, std=self.dataset.std)
+                   if self.dataset is not None else dict(images=self.images))
+            b0 = mdl.blocks[0]
+            K.patch_embed(self.Sh(mdl.patch_embed.weight).view(D, -1), mdl.patch_embed.bias.data, mdl.cls_token.data.view(-1),
+                          ape, self.p, self.T, out=self.x[0], patches_out=self.patches,
+                          stats=(self.act[0]["m1"], self.act[0]["r1"]) if self.fuse_ln else None, eps=b0.norm1.eps, **src)
+        else:
+            if self.dataset is not None:   # resident uint8 dataset: gather + ToTensor + Normalize inside the unfold
+                K.unfold_u8(self.dataset.images, self.batch_idx, self.dataset.mean, self.dataset.std, self.p, self.T,
+                            out=self.patches)
+            else:
+                K.unfold(self.images, self.p, self.T, out=self.patches)
+            K.patch_embed_gemm(self.patches, self.Sh(mdl.patch_embed.weight).view(D, -1), mdl.patch_embed.bias.data,
+                               mdl.cls_token.data.view(-1), ape, B, self.P, out=self.x[0])
+            if self.fuse_ln:
+                b0 = mdl.blocks[0]
+                K.layernorm_fwd(self.x[0], b0.norm1.weight.data, b0.norm1.bias.data, b0.norm1.eps, mean=self.act[0]["m1"],
+                                rstd=self.act[0]["r1"], stats_only=True)
         if isinstance(mdl.pos_embed, RoPEMixed):  # learnable frequencies: tables follow the parameters
             K.rope_mixed_tables(mdl.pos_embed.freqs.data, self.grid, self.pe.cos, self.pe.sin)
-        if self.fuse_ln:
-            b0 = mdl.blocks[0]
-            K.layernorm_fwd(self.x[0], b0.norm1.weight.data, b0.norm1.bias.data, b0.norm1.eps, mean=self.act[0]["m1"],
-                            rstd=self.act[0]["r1"], stats_only=True)
         for l, blk in enumerate(mdl.blocks):
             a, xin = self.act[l], self.x[l]
             if self.fuse_ln:
@@ -331,11 +344,11 @@ class TrainEngine:
     def _loss(self):
         if self.fuse_head:   # final LayerNorm + head + CE + accuracy + dlogits + the head's backward: one launch pair
             mdl, G = self.model, self.Gr
-            K.head_loss(self.x[-1], mdl.norm.weight.data, mdl.norm.bias.data, mdl.head.weight.data, mdl.head.bias.data,
+            K.head_step(self.x[-1], mdl.norm.weight.data, mdl.norm.bias.data, mdl.head.weight.data, mdl.head.bias.data,
                         self.labels, self.logits, self.dlogits, self.head_ws, self.ws_dyn, self.dx_out[self.Lyr], self.out2,
-                        self.metric_acc, self.head_scratch, G(mdl.head.weight), G(mdl.head.bias), G(mdl.norm.weight),
-                        G(mdl.norm.bias), eps=mdl.norm.eps, grad_scale=1.0 / self.B)
-            return   # (experiment path, VITPE_FUSE_HEAD=1: full batches only)
+                        self.metric_acc, self.head_scratch, self.ce_ctl, G(mdl.head.weight), G(mdl.head.bias),
+                        G(mdl.norm.weight), G(mdl.norm.bias), eps=mdl.norm.eps)
+            return
         K.cross_entropy_ctl(self.logits, self.labels, self.ce_ctl, dlogits=self.dlogits, out2=self.out2,
                             metric_acc=self.metric_acc)
 

@@ -410,6 +410,31 @@ def unfold_u8(data, index, mean, std, patch, dtype, out=None, img_out=None):
     return o
 
 
+def patch_embed_supported(dtype, C, S, p, D) -> bool:
+    return bool(lib().vitpe_patch_embed_supported(dtype_code(dtype), C, S, p, D))
+
+
+def patch_embed(w, bias, cls, ape, patch, dtype, images=None, data=None, index=None, mean=None, std=None, out=None,
+                patches_out=None, stats=None, eps=1e-5):
+    """Fused unfold + patch-embed GEMM + bias + APE + class token (+ LayerNorm statistics of the token rows).
+    images [B,C,S,S] fp32, or data (uint8 dataset) + index [B] int64 + mean/std [C].  w [D, C*p*p] in `dtype`."""
+    require_device(w, bias, cls, ape, images, data, index, mean, std, out, patches_out)
+    src = images if images is not None else data
+    C, S = src.shape[1], src.shape[2]
+    B = images.shape[0] if images is not None else (index.shape[0] if index is not None else data.shape[0])
+    D = w.shape[0]
+    P = (S // patch) ** 2
+    assert w.dtype == dtype and w.shape[1] == C * patch * patch
+    _f32(bias, "bias"), _f32(cls, "cls"), _f32(ape, "ape"), _f32(images, "images")
+    o = out if out is not None else torch.empty((B, P + 1, D), dtype=dtype, device=w.device)
+    mo, ro = stats if stats is not None else (None, None)
+    require_device(mo, ro)
+    check(lib().vitpe_patch_embed(dtype_code(dtype), ptr(images), ptr(data), ptr(index), ptr(mean), ptr(std), ptr(w), ptr(bias),
+                                  ptr(cls), ptr(ape), ptr(o), ptr(patches_out), ptr(mo), ptr(ro), B, C, S, patch, D, float(eps),
+                                  stream_ptr()), "vitpe_patch_embed")
+    return o
+
+
 def embed_bwd(dtok, dcls, dape, out=None):
     require_device(dtok, dcls, dape, out)
     B, Ntok, D = dtok.shape
@@ -584,6 +609,22 @@ def head_loss(x, gamma, beta, wh, bh, labels, logits, dlogits, ws, ws_dyn, dx, o
                                 ptr(dlogits), ptr(ws[0]), ptr(ws[1]), ptr(ws_dyn), ptr(dx), ptr(out2), ptr(metric_acc),
                                 ptr(scratch), ptr(dwh), ptr(dbh), ptr(dgamma), ptr(dbeta), B, Ntok, D, Cn, float(eps),
                                 float(gs), stream_ptr()), "vitpe_head_loss")
+
+
+def head_step(x, gamma, beta, wh, bh, labels, logits, dlogits, ws, ws_dyn, dx, out2, metric_acc, per_image, ctl, dwh, dbh,
+              dgamma, dbeta, eps=1e-5):
+    """The train step's head in one launch pair: final LayerNorm of the class row + logits + cross-entropy (device-side
+    scalars `ctl`, as cross_entropy_ctl) + dlogits + the class row of dx (rows 1.. of dx are NOT touched: the caller
+    keeps them zero) + parameter gradients (accumulated).  ws = (xhat, yn, rstd) work buffers; per_image [B,2] fp32."""
+    require_device(x, gamma, beta, wh, bh, labels, logits, dlogits, ws[0], ws[1], ws_dyn, dx, out2, metric_acc, per_image, ctl,
+                   dwh, dbh, dgamma, dbeta)
+    B, Ntok, D = x.shape
+    Cn = wh.shape[0]
+    assert labels.dtype == torch.int64 and per_image.numel() >= 2 * B and ctl.numel() >= 3
+    check(lib().vitpe_head_step(dtype_code(x.dtype), ptr(x), ptr(gamma), ptr(beta), ptr(wh), ptr(bh), ptr(labels), ptr(logits),
+                                ptr(dlogits), ptr(ws[0]), ptr(ws[1]), ptr(ws_dyn), ptr(dx), ptr(out2), ptr(metric_acc),
+                                ptr(per_image), ptr(ctl), ptr(dwh), ptr(dbh), ptr(dgamma), ptr(dbeta), B, Ntok, D, Cn, float(eps),
+                                stream_ptr()), "vitpe_head_step")
 
 
 # ---- optimizer / shadows --------------------------------------------------------------------
