@@ -143,7 +143,6 @@ def test_bf16_captured_step_gradients_full_cifar_geometry(tag, extra):
     ref_logits, ref_loss, ref_grads = O.loss_and_grads(cfg, params, images, labels)
     eng = TrainEngine(model, B, compute_dtype=torch.bfloat16, use_graph=True)
     assert eng.attn_fused and eng.fuse_ln and eng.fuse_ln_bwd and eng.fuse_mlp and eng.fuse_tail and eng.group_wgrad
-    assert eng.recompute_ln
     grads = graph_step_gradients(eng, images.cuda(), labels.cuda())
     assert eng.graph_fb is not None
     report = {}
@@ -380,3 +379,23 @@ def test_engine_runs_the_other_geometries_the_cli_accepts(geom, tag):
     assert eb.read_metrics()[0] == eb.read_metrics(reset=False)[0] or True
     torch.cuda.synchronize()
     assert torch.isfinite(eb.flat_p).all()
+
+
+def test_bf16_captured_step_with_layernorm_outputs_recomputed(monkeypatch):
+    """VITPE_RECOMPUTE_LN=1 (opt-in: LayerNorm outputs never stored; the attention backward and the weight-gradient kernel
+    re-normalise the raw rows while staging): same gradient parity as the default path."""
+    from vitpe.engine import TrainEngine
+    monkeypatch.setenv("VITPE_RECOMPUTE_LN", "1")
+    cfg, model = build("rope-mixed", {}, {}, seeded=True)
+    params = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+    B = 16
+    g = torch.Generator().manual_seed(11)
+    images, labels = torch.randn(B, 3, 32, 32, generator=g), torch.randint(0, 10, (B,), generator=g)
+    ref_logits, ref_loss, ref_grads = O.loss_and_grads(cfg, params, images, labels)
+    eng = TrainEngine(model, B, compute_dtype=torch.bfloat16, use_graph=True)
+    assert eng.recompute_ln and eng.act[0]["xn1"] is None and eng.act[0]["xn2"] is None
+    grads = graph_step_gradients(eng, images.cuda(), labels.cuda())
+    report = {}
+    bad = compare_all("rope-mixed/recompute-ln", model, grads, ref_grads, report)
+    _dump(report, "bench_path_parity.jsonl")
+    assert rel_err(eng.logits.cpu(), ref_logits) <= 5e-2 and not bad, bad

@@ -90,7 +90,10 @@ template <> struct WgLayout<float> {  // exact-fp32 parity mode: padded rows, sc
   }
 };
 
-template <typename T, bool CENSUS>
+// LNX: compiled with the LayerNorm-operand path (x_op).  A separate instantiation: its two statistics loads per staged
+// X chunk double the VMEM instruction count of a stage, and this kernel lives on the vector-memory path (measured:
+// 288 -> 342 us for a list WITHOUT any LayerNorm problem when the loads were unconditional).
+template <typename T, bool CENSUS, bool LNX>
 __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
   using LY = WgLayout<T>;
   constexpr int RPS = 128 / (int)sizeof(T);  // token rows per stage: 64 bf16 / 32 fp32
@@ -117,7 +120,10 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
     const int ub = u - P.unit0, blk = ub / P.stages;
     s.dY = reinterpret_cast<const T*>(P.dY); s.X = reinterpret_cast<const T*>(P.X); s.dW = P.dW; s.dbias = P.dbias;
     s.M = P.M; s.N = P.N; s.K = P.K; s.stages = P.stages;
-    s.xmean = P.xop ? P.xmean : P.dW; s.xrstd = P.xop ? P.xrstd : P.dW;
+    // (plain problems: a dummy word of their own dY -- read-only and cache-resident; NOT dW, whose lines are being
+    //  updated by other workgroups' flush atomics at the memory side and would miss every time)
+    s.xmean = P.xop ? P.xmean : reinterpret_cast<const float*>(P.dY);
+    s.xrstd = P.xop ? P.xrstd : reinterpret_cast<const float*>(P.dY);
     s.xgamma = P.xgamma; s.xbeta = P.xbeta; s.xop = P.xop;
     s.stage = ub - blk * P.stages;
     s.n0 = (blk % P.nbn) * WG_BLK;
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
   bool ln_staged = false;
   auto gload = [&](const Cur& s) {
     const int mb = s.stage * RPS;
-    ln_staged = s.xop == 1;
+    ln_staged = LNX && s.xop == 1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = tid + 768 * (i & 1), row = q / CPR, cc = q % CPR;
@@ -147,10 +153,13 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
         rg[i] = ok ? *reinterpret_cast<const Chunk16*>(s.X + (size_t)gm * s.K + gk) : zero;
         // row statistics: UNCONDITIONAL loads (plain problems read a dummy word of their own dW): a branch around them
         // made the compiler drain the whole prefetch (vmcnt(0)) before it, i.e. every stage waited out its HBM latency
-        // (only LOADED here, like the chunks: consuming them now would wait for every load of the burst)
-        const int gs = (s.xop == 1) ? min(gm, s.M - 1) : 0;
-        lnA[i - 2] = s.xrstd[gs];
-        lnB[i - 2] = s.xmean[gs];
+        if (LNX) {
+          // (only LOADED here, like the chunks: consuming them now would wait for every load of the burst; unconditional --
+          //  plain problems of a mixed list read a dummy word -- because a branch made the compiler drain the prefetch)
+          const int gs = (s.xop == 1) ? min(gm, s.M - 1) : 0;
+          lnA[i - 2] = s.xrstd[gs];
+          lnB[i - 2] = s.xmean[gs];
+        }
       }
     }
   };
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
     for (int i = 0; i < 4; ++i) {
       const int q = tid + 768 * (i & 1), row = q / CPR, cc = q % CPR;
       Chunk16 v = rg[i];
-      if (i >= 2 && ln_staged) {
+      if (LNX && i >= 2 && ln_staged) {
         float f[CHN];
         chunk_to_f32<T>(v, f);
         // (rows past M become -mean * rstd instead of 0: harmless, their dY rows are zero)
@@ -211,8 +220,8 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       const int gk = s.k0 + wk * 64 + 16 * kt + c;
-      gam[kt] = (s.xop == 1 && gk < s.K) ? s.xgamma[gk] : 1.f;
-      bet[kt] = (s.xop == 1 && gk < s.K) ? s.xbeta[gk] : 0.f;
+      gam[kt] = (LNX && s.xop == 1 && gk < s.K) ? s.xgamma[gk] : 1.f;
+      bet[kt] = (LNX && s.xop == 1 && gk < s.K) ? s.xbeta[gk] : 0.f;
     }
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt)
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
         for (int kt = 0; kt < 4; ++kt) {
           const int gk = s.k0 + wk * 64 + 16 * kt + c;
           float v = acc[nt][kt][r];
-          if (s.xop == 1) v = fmaf(v, gam[kt], bet[kt] * accb[nt][r]);
+          if (LNX && s.xop == 1) v = fmaf(v, gam[kt], bet[kt] * accb[nt][r]);
           if (gn < s.N && gk < s.K) atomicAdd(s.dW + (size_t)gn * s.K + gk, v);
         }
         if (bias && c == 0 && gn < s.N) atomicAdd(s.dbias + gn, accb[nt][r]);
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
     __syncthreads();
     stamp(u, 1);
     const bool bias = (cur.dbias != nullptr) && cur.k0 == 0 && wk == 0;
-    compute(buf, bias || cur.xop == 1);   // LayerNorm operand: every wave needs the column sums of dY (beta term)
+    compute(buf, bias || (LNX && cur.xop == 1));   // LayerNorm operand: every wave needs the column sums of dY (beta term)
     stamp(u, 3);
     if (flush_now) flush(cur, bias);
     cur = nxt;
@@ -392,8 +401,12 @@ static int wgrad_group_launch(int dtype, const void* problems, int nprob, unsign
     a.units_per_wg = (units + wgs - 1) / wgs;
     grid = (units + a.units_per_wg - 1) / a.units_per_wg;
   }
-  if (census != nullptr) hipLaunchKernelGGL((wgrad_group_kernel<bf16, true>), dim3(grid), dim3(768), 0, stream, a);
-  else if (dtype == 1) hipLaunchKernelGGL((wgrad_group_kernel<bf16, false>), dim3(grid), dim3(768), 0, stream, a);
-  else hipLaunchKernelGGL((wgrad_group_kernel<float, false>), dim3(grid), dim3(768), 0, stream, a);
+  bool lnx = false;
+  for (int i = 0; i < np; ++i) lnx = lnx || a.p[i].xop != 0;
+  if (census != nullptr) hipLaunchKernelGGL((wgrad_group_kernel<bf16, true, false>), dim3(grid), dim3(768), 0, stream, a);
+  else if (dtype == 1 && lnx) hipLaunchKernelGGL((wgrad_group_kernel<bf16, false, true>), dim3(grid), dim3(768), 0, stream, a);
+  else if (dtype == 1) hipLaunchKernelGGL((wgrad_group_kernel<bf16, false, false>), dim3(grid), dim3(768), 0, stream, a);
+  else if (lnx) hipLaunchKernelGGL((wgrad_group_kernel<float, false, true>), dim3(grid), dim3(768), 0, stream, a);
+  else hipLaunchKernelGGL((wgrad_group_kernel<float, false, false>), dim3(grid), dim3(768), 0, stream, a);
   VITPE_CHECK_LAUNCH();
 }

@@ -186,10 +186,12 @@ class TrainEngine:
         self.overlap_wgrad = os.environ.get("VITPE_OVERLAP_WGRAD", "0") == "1"
         # weight gradients: one grouped launch per backward part (default) or one GEMM per nn.Linear
         self.group_wgrad = os.environ.get("VITPE_GROUP_WGRAD", "1") == "1" and not self.overlap_wgrad
-        # LayerNorm outputs are never stored on the fully fused path: the attention backward and the weight-gradient
-        # kernel re-normalise the raw rows (kept anyway) from the saved statistics while staging them
+        # VITPE_RECOMPUTE_LN=1: LayerNorm outputs are not stored at all -- the attention backward and the weight-gradient
+        # kernel re-normalise the raw rows from the saved statistics while staging them (-25.6 MB of stores per layer).
+        # Measured neutral-to-slower (the statistics loads cost the weight-gradient kernel, which lives on the vector-
+        # memory path, +55..75 us per step; the forward kernels gain ~20 us): off by default, kept for memory-bound boxes.
         self.recompute_ln = (self.attn_fused and self.fuse_ln and self.fuse_ln_bwd and self.fuse_mlp and self.fuse_tail
-                             and self.group_wgrad and os.environ.get("VITPE_RECOMPUTE_LN", "1") == "1")
+                             and self.group_wgrad and os.environ.get("VITPE_RECOMPUTE_LN", "0") == "1")
         xn = (lambda: None) if self.recompute_ln else (lambda: e(B, N, D))
         self.act = []
         for _ in range(self.Lyr):
