@@ -37,6 +37,7 @@
 // the q scale and into the staged bias table / coefficients), keys are masked only in the last
 // key tile, and every address is a compile-time offset from a per-lane base.
 #include "attn_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace vitpe {
@@ -486,6 +487,417 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, (sizeof(T) == 2 ? 3 : 1)) void
 }
 
 // =========================================================================================
+// Backward, register-resident (bf16 throughput build): the forward's mapping -- one wave per (image, head), two images
+// per workgroup, no barrier after the staging one -- applied to the hand-derived backward:
+//   staging : LayerNorm'd tokens x and the output gradient dO of the image -> LDS (both [token][D] rows)
+//   project : v~, k~ (swapped: keys on the lane), K^T (un-swapped k~: features on the lane), q~ (swapped), later Q^T
+//   step 1  : per 16-query tile on the SWAPPED tiles (lane = query): S^T, P^T, dP^T = V dO^T, delta, dS^T, the
+//             positional-parameter gradients, dQ^T = K^T dS^T, inverse rotation, store; lse / delta -> wave-private LDS
+//   step 2  : per 16-key tile on the PLAIN tiles (lane = key): S = Q K^T and dP = dO V^T re-derived from the same
+//             fragments, P from the saved lse, dS; dV^T = dO^T P and dK^T = Q^T dS with the accumulators as operands
+//             (dO^T by transposed LDS reads), inverse rotation, store.
+// k and q are each projected twice (once per orientation) instead of being parked in LDS and read back transposed:
+// 120 extra MFMAs per wave buy a kernel whose q/k/v never touch LDS and whose twelve waves per CU run unsynchronised.
+// =========================================================================================
+template <typename T, typename C, int NTH>
+VITPE_DEV void stage_rows_plain(const T* src, T* dst, int ld, int N, int tid) {
+  constexpr int CHN = CH<T>::n, D = C::DD, CPRW = D / CHN, RPP = NTH / CPRW, ITERS = C::NP / RPP;
+  const int cc = tid % CPRW, r0 = tid / CPRW;
+  const Chunk16 zero = {0u, 0u, 0u, 0u};
+  Chunk16 v[ITERS];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int row = r0 + it * RPP;
+    v[it] = *reinterpret_cast<const Chunk16*>(src + (size_t)min(row, N - 1) * D + cc * CHN);
+    if (row >= N) v[it] = zero;
+  }
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) *reinterpret_cast<Chunk16*>(dst + (r0 + it * RPP) * ld + cc * CHN) = v[it];
+}
+
+template <int HD, int D, int MT, int KM, int NTOK, int IPW, bool LNF, bool MIXED>
+__global__ __launch_bounds__(64 * (D / HD) * IPW, 3) void attn_bwd_reg_kernel(AttnArgs a) {
+  using T = bf16;
+  using C = AttnCfg<T, HD, D, MT, 1, NTOK>;
+  constexpr int NT = C::NT, KS = C::KS, HC = C::HC, SC = C::SC, NTH = 64 * C::H;
+  static_assert(NT == 2 && HC == 1, "head dimension 32");
+  constexpr int CSLD = HD / 2 + 8;
+  constexpr int FRAG = 64 * 8;                       // elements of one parked fragment (lane-linear 16 B per lane)
+  // x tiles; once the projections are done (second barrier) the region is re-used as the waves' dO-fragment scratch
+  constexpr int XS_ELEMS = IPW * C::NP * C::LDX, DOS_ELEMS = IPW * C::H * MT * FRAG;
+  __shared__ __attribute__((aligned(16))) T xs_all[XS_ELEMS > DOS_ELEMS ? XS_ELEMS : DOS_ELEMS];
+  __shared__ __attribute__((aligned(16))) T qs_all[IPW * C::H * MT * FRAG];   // q~ fragments of every wave
+  __shared__ __attribute__((aligned(16))) float s_tab[KM == KM_RELATIVE ? C::H * C::TABLD : 4];
+  __shared__ __attribute__((aligned(16))) float s_coef[KM == KM_POLY ? C::PESZ : 4];
+  __shared__ __attribute__((aligned(16))) float s_cos[KM == KM_ROPE ? C::NP * CSLD : 4];
+  __shared__ __attribute__((aligned(16))) float s_sin[KM == KM_ROPE ? C::NP * CSLD : 4];
+  __shared__ __attribute__((aligned(16))) float s_stat[IPW * C::H * 2 * C::NP];   // per wave: [lse2 | delta][token]
+  __shared__ float s_dtab[KM == KM_RELATIVE ? C::H * C::TABLD : 4];   // per workgroup (both images)
+  __shared__ float s_dcoef[C::H * (C::MAXDEG + 1)];
+  __shared__ float s_dfreq[2 * C::H * (HD / 2)];
+
+  const int N = C::ntok(a), P = N - 1;
+  const int lane = threadIdx.x & 63;
+  const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int img = wave_all / C::H, h = wave_all % C::H;
+  const int b_raw = blockIdx.x * IPW + img;
+  const bool live = b_raw < a.B;
+  const int b = live ? b_raw : a.B - 1;
+  const int tid_img = threadIdx.x % NTH;
+  T* const xs = xs_all + img * C::NP * C::LDX;
+  T* const qsw = qs_all + wave_all * MT * FRAG + lane * 8;     // this wave's parked q~ fragments (+ tile * FRAG)
+  T* const dsw = xs_all + wave_all * MT * FRAG + lane * 8;     // this wave's parked dO fragments (after barrier 2)
+  float* const lse_w = s_stat + (img * C::H + h) * 2 * C::NP;
+  float* const del_w = lse_w + C::NP;
+  float* const dtab_i = s_dtab;
+  float* const dcoef_i = s_dcoef;
+  float* const dfreq_i = s_dfreq;
+  const int c = lane & 15, g = lane >> 4;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  constexpr bool mixed = (KM == KM_ROPE) && MIXED;   // (compile-time: the frequency-gradient code costs the axial build 100 spills)
+
+  const T* const Wh = reinterpret_cast<const T*>(a.wqkv) + ((size_t)h * 3 * NT * KS * 64 + lane) * 8;
+  auto wload = [&](Frag<T> (&w)[NT][KS], int mat) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) w[nt][ks] = ld_frag(Wh + (size_t)((mat * NT + nt) * KS + ks) * 64 * 8);
+  };
+  Frag<T> w[NT][KS];
+  wload(w, 2);                                            // Wv under the staging
+  stage_tokens_fwd<T, C, KM, NTH, LNF>(a, b, xs, s_tab, s_coef, tid_img, false, IPW == 1 || img == 0);
+  if (KM == KM_ROPE && !mixed) {   // axial table by TOKEN, identity rows for the class token and the padding
+    constexpr int F4 = HD / 8;
+    for (int q = threadIdx.x; q < C::NP * F4; q += NTH * IPW) {
+      const int f4 = q % F4, row = q / F4;
+      f32x4 cv = {1.f, 1.f, 1.f, 1.f}, sv = {0.f, 0.f, 0.f, 0.f};
+      if (row >= 1 && row < N) {
+        cv = *reinterpret_cast<const f32x4*>(a.cos + (size_t)(row - 1) * (HD / 2) + 4 * f4);
+        sv = *reinterpret_cast<const f32x4*>(a.sin + (size_t)(row - 1) * (HD / 2) + 4 * f4);
+      }
+      *reinterpret_cast<f32x4*>(&s_cos[row * CSLD + 4 * f4]) = cv;
+      *reinterpret_cast<f32x4*>(&s_sin[row * CSLD + 4 * f4]) = sv;
+    }
+  }
+  if (KM == KM_RELATIVE)
+    for (int q = threadIdx.x; q < C::H * C::TABLD; q += NTH * IPW) s_dtab[q] = 0.f;
+  for (int q = threadIdx.x; q < C::H * (C::MAXDEG + 1); q += NTH * IPW) s_dcoef[q] = 0.f;
+  for (int q = threadIdx.x; q < 2 * C::H * (HD / 2); q += NTH * IPW) s_dfreq[q] = 0.f;
+  __syncthreads();
+
+  const T* const xrow = xs + c * C::LDX + 8 * g;
+  const size_t hoff = mixed ? (size_t)h * P * (HD / 2) : 0;
+  // cos / sin of token `tok`, features f .. f+3 (identity outside the patch tokens)
+  auto cs_vec = [&](int tok, int f, f32x4& cv, f32x4& sv) {
+    if (!mixed) {
+      cv = *reinterpret_cast<const f32x4*>(&s_cos[tok * CSLD + f]);
+      sv = *reinterpret_cast<const f32x4*>(&s_sin[tok * CSLD + f]);
+    } else {
+      const bool ok = tok >= 1 && tok < N;
+      const size_t o = hoff + (size_t)(min(max(tok, 1), N - 1) - 1) * (HD / 2) + f;
+      const f32x4 cg = *reinterpret_cast<const f32x4*>(a.cos + o), sg = *reinterpret_cast<const f32x4*>(a.sin + o);
+      cv = ok ? cg : (f32x4){1.f, 1.f, 1.f, 1.f};
+      sv = ok ? sg : z4;
+    }
+  };
+  // swapped projection of token tile tt: acc[nt][r] = (x W^T)[token 16tt + c][feature 16nt + 4g + r]; rotate; scale
+  auto proj_sw = [&](int tt, bool rope, float sc, Frag<T>& dst) {
+    Frag<T> xf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xf[ks] = ld_frag(xrow + 16 * tt * C::LDX + 32 * ks);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[NT] = {z4, z4};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) mma(w[nt][ks], xf[ks], acc[nt]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (KM == KM_ROPE && rope) {
+      f32x4 cv, sv;
+      cs_vec(16 * tt + c, 4 * g, cv, sv);
+      const f32x4 x1 = acc[0], x2 = acc[1];
+      acc[0] = x1 * cv - x2 * sv;
+      acc[1] = x1 * sv + x2 * cv;
+    }
+    dst = acc_to_frag<T>(acc[0] * sc, acc[1] * sc);
+  };
+  // Transposition on the matrix core.  A swapped fragment f[tt] holds X[token 16tt + c][feature phi(g, t)] (phi = the
+  // acc_to_frag order: t < 4 -> 4g + t, t >= 4 -> 16 + 4g + t - 4); multiplied by the 0/1 selection matrix E_nt
+  // (E_nt[k = (g, t)][col c'] = 1 iff phi(g, t) == 16nt + c') it comes out as acc[r] = X[token 16tt + 4g + r][feature
+  // 16nt + c]: the token index in the registers, where acc_to_frag turns tile pairs into the operand of a product that
+  // contracts over TOKENS (K^T for dQ, Q^T for dK, dO^T for dV).  Exact (one 1.0 per column), 2 MFMAs per tile --
+  // instead of a second projection (12) or a round trip through a transposed LDS image.
+  Frag<T> e0, e1;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    e0.v[t] = (bf16)((t < 4 && 4 * g + t == c) ? 1.0f : 0.0f);
+    e1.v[t] = (bf16)((t >= 4 && 4 * g + t - 4 == c) ? 1.0f : 0.0f);
+  }
+  auto transpose_pair = [&](const Frag<T>& fa, const Frag<T>* fb, Frag<T>& d0, Frag<T>& d1) {
+    f32x4 a0 = z4, a1 = z4, b0 = z4, b1 = z4;
+    mma(fa, e0, a0);
+    mma(fa, e1, a1);
+    if (fb != nullptr) { mma(*fb, e0, b0); mma(*fb, e1, b1); }
+    d0 = acc_to_frag<T>(a0, b0);
+    d1 = acc_to_frag<T>(a1, b1);
+  };
+
+  const float qsc = a.scale * LOG2E;
+  Frag<T> vkf[MT], kf[MT];
+#pragma unroll
+  for (int tt = 0; tt < MT; ++tt) proj_sw(tt, false, 1.0f, vkf[tt]);
+  wload(w, 1);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int tt = 0; tt < MT; ++tt) proj_sw(tt, true, 1.0f, kf[tt]);
+  wload(w, 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int tt = 0; tt < MT; ++tt) {   // q~ fragments are parked (lane-linear: conflict-free 16-B accesses)
+    Frag<T> qf;
+    proj_sw(tt, true, qsc, qf);
+    *reinterpret_cast<bf16x8*>(qsw + tt * FRAG) = qf.v;
+  }
+  __syncthreads();                     // every wave is done with the x tiles: the region becomes the dO scratch
+  if (!live) return;
+  {  // this head's dO rows as operand fragments: lane (c, g) <- dO[token 16tt + c][features 4g..4g+3 | 16+4g..]
+    const T* dog = reinterpret_cast<const T*>(a.dout) + (size_t)b * N * D + h * HD;
+    Frag<T> df[MT];
+#pragma unroll
+    for (int tt = 0; tt < MT; ++tt) {
+      const int tok = 16 * tt + c;
+      bf16x4 lo = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f}, hi = lo;
+      if (tok < N) {
+        lo = *reinterpret_cast<const bf16x4*>(dog + (size_t)tok * D + 4 * g);
+        hi = *reinterpret_cast<const bf16x4*>(dog + (size_t)tok * D + 16 + 4 * g);
+      }
+      df[tt].v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int tt = 0; tt < MT; ++tt) *reinterpret_cast<bf16x8*>(dsw + tt * FRAG) = df[tt].v;
+  }
+  auto qf_load = [&](int tt) { Frag<T> f; f.v = *reinterpret_cast<const bf16x8*>(qsw + tt * FRAG); return f; };
+  auto dof_load = [&](int tt) { Frag<T> f; f.v = *reinterpret_cast<const bf16x8*>(dsw + tt * FRAG); return f; };
+  Frag<T> ktf[NT][SC];
+#pragma unroll
+  for (int scx = 0; scx < SC; ++scx)
+    transpose_pair(kf[2 * scx], (2 * scx + 1 < MT) ? &kf[(2 * scx + 1 < MT) ? 2 * scx + 1 : 0] : nullptr, ktf[0][scx], ktf[1][scx]);
+
+  T* const dqg = reinterpret_cast<T*>(a.out) + (size_t)b * N * 3 * D + h * HD;
+  // 16-B stores of a swapped-orientation result pair (features 16dt + 4g + r of token c): see the forward kernel
+  auto store_pair = [&](T* rowp, const f32x4& o0, const f32x4& o1, bool ok) {
+    uint32_t lo[2], hi[2];
+#pragma unroll
+    for (int w2 = 0; w2 < 2; ++w2) {
+      bf16x2 pa, pb;
+      pa[0] = (bf16)o0[2 * w2]; pa[1] = (bf16)o0[2 * w2 + 1];
+      pb[0] = (bf16)o1[2 * w2]; pb[1] = (bf16)o1[2 * w2 + 1];
+      const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, pa), __builtin_bit_cast(uint32_t, pb), false, false);
+      lo[w2] = r[0]; hi[w2] = r[1];
+    }
+    const int f0 = 16 * (g & 1) + 8 * (g >> 1);
+    if (ok) *reinterpret_cast<Chunk16*>(rowp + f0) = (Chunk16){lo[0], lo[1], hi[0], hi[1]};
+  };
+
+  // ---- step 1: query tiles on the swapped tiles --------------------------------------------------------------
+#pragma unroll
+  for (int it = 0; it < MT; ++it) {
+    __builtin_amdgcn_sched_barrier(0);
+    const int i = 16 * it + c;
+    const Frag<T> dof = dof_load(it), qfi = qf_load(it);
+    f32x4 s[MT], dp[MT];
+    float m = -1e30f;
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt) {
+      s[jt] = z4;
+      mma(kf[jt], qfi, s[jt]);
+      dp[jt] = z4;
+      mma(vkf[jt], dof, dp[jt]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * jt + 4 * g + r;
+        float v = s[jt][r];
+        if (KM == KM_RELATIVE || KM == KM_POLY) v += pe_bias2<C, KM>(a, s_tab, s_coef, h, i, j, N);
+        if (jt == MT - 1) v = (j < N) ? v : -1e30f;
+        s[jt][r] = v;
+        m = fmaxf(m, v);
+      }
+    }
+    m = xg_max(m);
+    float l = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float p = __builtin_amdgcn_exp2f(s[jt][r] - m); s[jt][r] = p; l += p; }
+    l = xg_sum(l);
+    const float inv = __builtin_amdgcn_rcpf(l);
+    float dl = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s[jt][r] *= inv; dl += s[jt][r] * dp[jt][r]; }
+    dl = xg_sum(dl);
+    if (g == 0) { lse_w[i] = m + __builtin_amdgcn_logf(l); del_w[i] = dl; }   // v_log_f32 = log2
+    float cacc[C::MAXDEG + 1];
+#pragma unroll
+    for (int k = 0; k <= C::MAXDEG; ++k) cacc[k] = 0.f;
+    const bool qvalid = (it < MT - 1) || (i < N);
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * jt + 4 * g + r;
+        const bool valid = qvalid && ((jt < MT - 1) || (j < N));
+        const float ds = valid ? s[jt][r] * (dp[jt][r] - dl) : 0.f;
+        dp[jt][r] = ds;
+        if (KM == KM_POLY) {
+          if (valid && i >= 1 && j >= 1) {
+            const float x = (float)pe_l1<C>(s_coef, i, j);
+            float pw = 1.f;
+#pragma unroll
+            for (int k = 0; k <= C::MAXDEG; ++k) { if (k <= a.degree) cacc[k] += ds * pw; pw *= x; }
+          }
+        }
+      }
+    if (KM == KM_RELATIVE) {
+#pragma unroll
+      for (int jt = 0; jt < MT; ++jt) {
+        float d0, d1;
+        tile_diag_sums(dp[jt], lane, d0, d1);
+        const int idx0 = 16 * (it - jt) + c + N - 1;
+        if (g == 0) {
+          if (idx0 >= 0 && idx0 <= 2 * N - 2) atomicAdd(&dtab_i[h * C::TABLD + idx0], d0);
+          if (c >= 1 && idx0 - 16 >= 0 && idx0 - 16 <= 2 * N - 2) atomicAdd(&dtab_i[h * C::TABLD + idx0 - 16], d1);
+        }
+      }
+    }
+    if (KM == KM_POLY) {
+#pragma unroll
+      for (int k = 0; k <= C::MAXDEG; ++k)
+        if (k <= a.degree) {
+          const float t = wave_sum(cacc[k]);
+          if (lane == 0) atomicAdd(&dcoef_i[(a.coeff_per_head ? h : 0) * (C::MAXDEG + 1) + k], t);
+        }
+    }
+    // dQrot^T[d][i] / scale = sum_j K^T[d][j] dS^T[j][i]
+    f32x4 dqa[NT] = {z4, z4};
+#pragma unroll
+    for (int scx = 0; scx < SC; ++scx) {
+      const Frag<T> bs = acc_to_frag<T>(dp[2 * scx], (2 * scx + 1 < MT) ? dp[(2 * scx + 1 < MT) ? 2 * scx + 1 : 0] : z4);
+#pragma unroll
+      for (int dt = 0; dt < NT; ++dt) mma(ktf[dt][scx], bs, dqa[dt]);
+    }
+    if (mixed) {   // dL/dphase = (dq~2 q~1 - dq~1 q~2): q~ = the fragment this tile's logits were made from
+      const bool tok_ok = i >= 1 && i < N;
+      f32x4 dph;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dph[r] = dqa[1][r] * (float)qfi.v[r] - dqa[0][r] * (float)qfi.v[4 + r];
+      mixed_freq_grad_tile(dfreq_i, dph, i, tok_ok, 16 * it, h, C::H, P, a.grid, HD / 2, 4 * g, LN2, lane);
+    }
+    if (KM == KM_ROPE) {   // inverse rotation (identity rows outside the patch tokens)
+      f32x4 cv, sv;
+      cs_vec(min(i, C::NP - 1), 4 * g, cv, sv);
+      const f32x4 d1 = dqa[0], d2 = dqa[1];
+      dqa[0] = d1 * cv + d2 * sv;
+      dqa[1] = d2 * cv - d1 * sv;
+    }
+    store_pair(dqg + (size_t)i * 3 * D, dqa[0] * a.scale, dqa[1] * a.scale, qvalid);
+  }
+
+  // ---- Q^T and dO^T operands for dK / dV (K^T is dead now) -------------------------------------------------------
+  Frag<T> qtf[NT][SC], dotf[NT][SC];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int scx = 0; scx < SC; ++scx) {
+    const bool two = 2 * scx + 1 < MT;
+    const Frag<T> qa = qf_load(2 * scx), qb = qf_load(two ? 2 * scx + 1 : 0);
+    transpose_pair(qa, two ? &qb : nullptr, qtf[0][scx], qtf[1][scx]);
+    const Frag<T> da = dof_load(2 * scx), db = dof_load(two ? 2 * scx + 1 : 0);
+    transpose_pair(da, two ? &db : nullptr, dotf[0][scx], dotf[1][scx]);
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // this wave's lse / delta stores (LDS operations of a wave complete in order)
+
+  // ---- step 2: key tiles on the plain tiles -------------------------------------------------------------------
+#pragma unroll
+  for (int jt = 0; jt < MT; ++jt) {
+    __builtin_amdgcn_sched_barrier(0);
+    const int j = 16 * jt + c;
+    const bool kvalid = (jt < MT - 1) || (j < N);
+    f32x4 p[MT], ds[MT];
+#pragma unroll
+    for (int it = 0; it < MT; ++it) {
+      const Frag<T> dof = dof_load(it), qfi = qf_load(it);
+      p[it] = z4;
+      mma(qfi, kf[jt], p[it]);             // S[query 16it + 4g + r][key j]
+      ds[it] = z4;
+      mma(dof, vkf[jt], ds[it]);           // dP[query][key]
+      const f32x4 lse = *reinterpret_cast<const f32x4*>(&lse_w[16 * it + 4 * g]);
+      const f32x4 dlv = *reinterpret_cast<const f32x4*>(&del_w[16 * it + 4 * g]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * it + 4 * g + r;
+        float sv = p[it][r];
+        if (KM == KM_RELATIVE || KM == KM_POLY) sv += pe_bias2<C, KM>(a, s_tab, s_coef, h, i, j, N);
+        const bool valid = kvalid && ((it < MT - 1) || (i < N));
+        const float pv = valid ? __builtin_amdgcn_exp2f(sv - lse[r]) : 0.f;
+        p[it][r] = pv;
+        ds[it][r] = pv * (ds[it][r] - dlv[r]);
+      }
+    }
+    f32x4 dva[NT] = {z4, z4}, dka[NT] = {z4, z4};
+#pragma unroll
+    for (int scx = 0; scx < SC; ++scx) {
+      const bool two = (2 * scx + 1 < MT);
+      const Frag<T> bp = acc_to_frag<T>(p[2 * scx], two ? p[two ? 2 * scx + 1 : 0] : z4);
+      const Frag<T> bs = acc_to_frag<T>(ds[2 * scx], two ? ds[two ? 2 * scx + 1 : 0] : z4);
+#pragma unroll
+      for (int dt = 0; dt < NT; ++dt) {
+        mma(dotf[dt][scx], bp, dva[dt]);
+        mma(qtf[dt][scx], bs, dka[dt]);
+      }
+    }
+    dka[0] *= LN2; dka[1] *= LN2;          // q~ carries scale * log2e
+    if (mixed) {
+      const bool tok_ok = j >= 1 && j < N;
+      f32x4 dph;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dph[r] = dka[1][r] * (float)kf[jt].v[r] - dka[0][r] * (float)kf[jt].v[4 + r];
+      mixed_freq_grad_tile(dfreq_i, dph, j, tok_ok, 16 * jt, h, C::H, P, a.grid, HD / 2, 4 * g, 1.0f, lane);
+    }
+    if (KM == KM_ROPE) {
+      f32x4 cv, sv;
+      cs_vec(min(j, C::NP - 1), 4 * g, cv, sv);
+      const f32x4 d1 = dka[0], d2 = dka[1];
+      dka[0] = d1 * cv + d2 * sv;
+      dka[1] = d2 * cv - d1 * sv;
+    }
+    store_pair(dqg + (size_t)j * 3 * D + D, dka[0], dka[1], kvalid);
+    store_pair(dqg + (size_t)j * 3 * D + 2 * D, dva[0], dva[1], kvalid);
+  }
+
+  // ---- positional-parameter gradients: accumulated per WORKGROUP in LDS (both images, all heads), flushed once -- the
+  // global adds all land on the same few hundred addresses, where an atomic costs ~12 ns serialised: one flush per
+  // workgroup instead of one per image halves them
+  __syncthreads();   // (waves of an idle image slot have exited: the barrier counts the running waves only)
+  // threads still running: the live images are the leading ones, so they are threadIdx.x < nrun
+  const int nrun = NTH * min(IPW, a.B - (int)blockIdx.x * IPW);
+  if (KM == KM_RELATIVE) {
+    for (int q = threadIdx.x; q < C::H * (2 * N - 1); q += nrun) {
+      const int hh = q / (2 * N - 1), i = q % (2 * N - 1);
+      atomicAdd(a.dtable + q, s_dtab[hh * C::TABLD + i]);
+    }
+  } else if (KM == KM_POLY) {
+    const int nh = a.coeff_per_head ? C::H : 1;
+    for (int q = threadIdx.x; q < nh * (a.degree + 1); q += nrun) {
+      const int hh = q / (a.degree + 1), k = q % (a.degree + 1);
+      atomicAdd(a.dcoeff + q, s_dcoef[hh * (C::MAXDEG + 1) + k]);
+    }
+  } else if (mixed) {
+    for (int q = threadIdx.x; q < 2 * C::H * (HD / 2); q += nrun) atomicAdd(a.dfreqs + q, s_dfreq[q]);
+  }
+}
+
+// =========================================================================================
 // Backward
 // =========================================================================================
 template <typename T, int HD, int D, int MT, int HPP, int KM, int NTOK>
@@ -847,6 +1259,23 @@ extern "C" int vitpe_pack_qkv_weights(int dtype, const float* wqkv, void* packed
 
 template <typename T, int HD, int D, int MT, int HPP, int KM, int NTOK>
 static int launch_attn3(bool bwd, const AttnArgs& a, hipStream_t s) {
+  static const bool bwd_lds = getenv("VITPE_ATTN_BWD_LDS") != nullptr;   // A/B switch: the LDS-tile backward of round 1
+  if constexpr (sizeof(T) == 2 && D / HD <= 6) {
+    if (bwd && !bwd_lds) {   // register-resident backward: one wave per (image, head), two images per workgroup
+      const dim3 grid((a.B + 1) / 2), block(64 * (D / HD) * 2);
+      const bool ln = a.ln_gamma != nullptr;
+      if constexpr (KM == KM_ROPE) {
+        if (a.mode == PE_ROPE_MIXED) {
+          if (ln) hipLaunchKernelGGL((attn_bwd_reg_kernel<HD, D, MT, KM, NTOK, 2, true, true>), grid, block, 0, s, a);
+          else hipLaunchKernelGGL((attn_bwd_reg_kernel<HD, D, MT, KM, NTOK, 2, false, true>), grid, block, 0, s, a);
+          VITPE_CHECK_LAUNCH();
+        }
+      }
+      if (ln) hipLaunchKernelGGL((attn_bwd_reg_kernel<HD, D, MT, KM, NTOK, 2, true, false>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((attn_bwd_reg_kernel<HD, D, MT, KM, NTOK, 2, false, false>), grid, block, 0, s, a);
+      VITPE_CHECK_LAUNCH();
+    }
+  }
   if (bwd)
     hipLaunchKernelGGL((attn_bwd_kernel<T, HD, D, MT, HPP, KM, NTOK>), dim3(a.B), dim3(384), 0, s, a);
   else {  // one wave per (image, head); bf16: two images per workgroup (see attn_fwd_kernel)
