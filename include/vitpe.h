@@ -162,6 +162,27 @@ int vitpe_block_tail_fwd(int dtype, const void* attn_out, const void* x_in, cons
                          void* xn_out, const void* W1, const float* b1, const void* W2, const float* b2,
                          void* u_out, void* h_out, void* out, float* mean_out, float* rstd_out, float eps2,
                          float eps_next, int M, int D, int HID, vitpe_stream_t stream);
+/* vitpe_block_tail2_fwd: the same function as vitpe_block_tail_fwd with each wave carrying one 16-token tile through
+ * the whole chain (hidden activation in registers between fc1 and fc2) and the weights read as MFMA fragments from
+ * fragment-major packed copies made by vitpe_pack_weight_frags:
+ *   Wp_packed = pack(attn.proj.weight [192,192], kchunk 192, phi 0)
+ *   W1_packed = pack(mlp.fc1.weight  [HID,192], kchunk 192, phi 1)
+ *   W2_packed = pack(mlp.fc2.weight  [192,HID], kchunk  32, phi 1)
+ * What it keeps of the hidden layer for backward is h_out = gelu(u) and gp_out = gelu'(u) [M,HID] (NOT u: the
+ * backward multiplies by the stored derivative, vitpe_block_tail_bwd with u_is_gprime = 1); pass both or, for
+ * inference, neither.  bf16, D = 192, HID % 64 == 0, 128 <= HID <= 1536 (vitpe_block_tail2_supported); otherwise
+ * hipErrorNotSupported.
+ * vitpe_pack_weight_frags: W fp32 [R,C] (R % 16 == 0, kchunk % 32 == 0, C % kchunk == 0) -> 1-KB fragments
+ * (64 lanes x 8 elements) at fragment index ((kc * R/16 + nt) * kchunk/32 + ks); lane 16g + cc, element e holds
+ * W[16nt + cc][kchunk*kc + 32ks + k], k = 8g + e (phi 0) or (e < 4 ? 4g + e : 16 + 4g + e - 4) (phi 1).          */
+int vitpe_pack_weight_frags(int dtype, const float* W, void* packed, int R, int C, int kchunk, int phi,
+                            vitpe_stream_t stream);
+int vitpe_block_tail2_supported(int dtype, int D, int HID);
+int vitpe_block_tail2_fwd(int dtype, const void* attn_out, const void* x_in, const void* Wp_packed, const float* bp,
+                          const float* gamma, const float* beta, void* x_mid, float* mean2, float* rstd2,
+                          void* xn_out, const void* W1_packed, const float* b1, const void* W2_packed,
+                          const float* b2, void* gp_out, void* h_out, void* out, float* mean_out, float* rstd_out,
+                          float eps2, float eps_next, int M, int D, int HID, vitpe_stream_t stream);
 /* vitpe_mlp_bwd: backward of that branch w.r.t. its input, same pipeline on the transposed weight shadows:
  *   du = (dy fc2.weight) * gelu'(u)   [M,HID], stored (the fc1 weight gradient reads it)
  *   dx = dy + LayerNorm'(du fc1.weight) ; dgamma / dbeta accumulated (fp32 atomics)
@@ -173,6 +194,12 @@ int vitpe_mlp_bwd(int dtype, const void* dy, const void* u, const void* W2t, con
 /* vitpe_block_tail_bwd: vitpe_mlp_bwd plus the data gradient of the attention projection in the same kernel:
  *   da = dx W_proj  [M,192]  (WpT = attn.proj.weight^T), the input of the attention backward.            */
 int vitpe_block_tail_bwd(int dtype, const void* dy, const void* u, const void* W2t, const void* W1t, const void* x,
+                         const float* mean, const float* rstd, const float* gamma, void* du, void* dx,
+                         float* dgamma, float* dbeta, const void* WpT, void* da, int M, int D, int HID,
+                         vitpe_stream_t stream);
+/* vitpe_block_tail_bwd_gp: the same with gp = gelu'(u) [M,HID] (saved by vitpe_block_tail2_fwd) in place of u:
+ *   du = (dy fc2.weight) * gp -- no erf evaluation in the backward.                                              */
+int vitpe_block_tail_bwd_gp(int dtype, const void* dy, const void* gp, const void* W2t, const void* W1t, const void* x,
                          const float* mean, const float* rstd, const float* gamma, void* du, void* dx,
                          float* dgamma, float* dbeta, const void* WpT, void* da, int M, int D, int HID,
                          vitpe_stream_t stream);

@@ -23,6 +23,17 @@ int vitpe_debug_wgrad_census(int dtype, const vitpe_wgrad_problem* problems, int
  * 4 k projected, 5 q projected, 6 end                                                                              */
 int vitpe_debug_attn_census(const void* xn, const void* wqkv, void* out, const float* cos, const float* sin,
                             int B, unsigned long long* census, vitpe_stream_t stream);
+/* phase census of the second-generation block tail (training instantiation with stamps; bf16, D = 192):
+ * census[(workgroup * 9 + wave) * 16 + slot] = s_memtime at 0 start, 1 first slab landed, 2 proj product done,
+ * 3 LayerNorm2 epilogue done, 4 period-0 barrier passed, 5 period 0 done, 6 periods 1.. done, 7 last barrier passed,
+ * 8 last fc2 product done, 9 end; slots 10 / 11 / 12 = ticks summed over periods 1.. in the barrier wait, the fc1
+ * product, the interleaved {fc2 || GELU} step.  exp: timing experiments with WRONG results (1 quarter of the LDS
+ * fragment reads, 2 no erf, 4 no hidden-layer stores, 7 all), 0 = the real kernel.                                                                        */
+int vitpe_debug_tail2_census(const void* attn_out, const void* x_in, const void* Wp_packed, const float* bp,
+                             const float* gamma, const float* beta, void* x_mid, float* mean2, float* rstd2,
+                             void* xn_out, const void* W1_packed, const float* b1, const void* W2_packed,
+                             const float* b2, void* gp_out, void* h_out, void* out, float* mean_out, float* rstd_out,
+                             int M, int HID, unsigned long long* census, int exp, vitpe_stream_t stream);
 #ifdef __cplusplus
 }
 #endif

@@ -293,6 +293,90 @@ def test_block_tail_forward_equals_proj_then_mlp(K, M):
     assert rel_err(mo.cpu(), o.mean(1)) < 1e-4
 
 
+def _frag_pack_ref(w, kchunk, phi):
+    """numpy restatement of vitpe_pack_weight_frags (include/vitpe.h)."""
+    import numpy as np
+    R, C = w.shape
+    ksc, ntr = kchunk // 32, R // 16
+    out = np.empty(R * C, dtype=np.float32)
+    idx = np.arange(R * C)
+    e, l, blk = idx & 7, (idx >> 3) & 63, idx >> 9
+    ks, nt, kc = blk % ksc, (blk // ksc) % ntr, blk // ksc // ntr
+    cc, g = l & 15, l >> 4
+    k = np.where(e < 4, 4 * g + e, 16 + 4 * g + e - 4) if phi else 8 * g + e
+    out[:] = w.numpy()[16 * nt + cc, kchunk * kc + 32 * ks + k]
+    return torch.from_numpy(out).view(R, C)
+
+
+@pytest.mark.parametrize("shape,kchunk,phi", [((192, 192), 192, 0), ((768, 192), 192, 1), ((192, 768), 32, 1), ((32, 64), 32, 1)])
+def test_pack_weight_frags_layout(K, shape, kchunk, phi):
+    w = rnd(*shape, seed=7)
+    for dt in (torch.bfloat16, torch.float32):
+        got = K.pack_weight_frags(dev(w), dt, kchunk, phi).float().cpu()
+        assert torch.equal(got, _frag_pack_ref(w, kchunk, phi).to(dt).float())
+
+
+@pytest.mark.parametrize("M,HID,save", [(650, 768, True), (130 * 2 + 5, 768, False), (33280, 768, True), (13, 128, True),
+                                        (144 * 3, 1536, True), (16 * 2048 + 16 * 40 + 3, 768, True)])
+def test_block_tail2_forward_equals_first_generation(K, M, HID, save):
+    """The wave-per-token-tile block tail (hidden activation in registers, packed weights by LDS-DMA) against the
+    first-generation kernel on the same operands, and against fp32 math on the rounded operands."""
+    D, bf = 192, torch.bfloat16
+    assert K.block_tail2_supported(bf, D, HID)
+    a_, x_in = rnd(M, D, seed=21), rnd(M, D, seed=22)
+    wp, bp = rnd(D, D, seed=23, scale=0.07), 0.1 * rnd(D, seed=24)
+    g, b = 1 + 0.1 * rnd(D, seed=25), 0.1 * rnd(D, seed=26)
+    w1, b1 = rnd(HID, D, seed=27, scale=0.08), 0.1 * rnd(HID, seed=28)
+    w2, b2 = rnd(D, HID, seed=29, scale=0.05), 0.1 * rnd(D, seed=30)
+    mo, ro = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    xn_out = torch.empty(M, D, device="cuda", dtype=bf)
+    wp_pk = K.pack_weight_frags(dev(wp), bf, 192, 0)
+    w1_pk = K.pack_weight_frags(dev(w1), bf, 192, 1)
+    w2_pk = K.pack_weight_frags(dev(w2), bf, 32, 1)
+    out, x_mid, m2, r2, gp, h = K.block_tail2_fwd(dev(a_, bf), dev(x_in, bf), wp_pk, dev(bp), dev(g), dev(b), w1_pk, dev(b1),
+                                                 w2_pk, dev(b2), xn_out=xn_out, stats=(mo, ro), save=save)
+    assert (h is not None) == save and (gp is not None) == save
+    if K.mlp_fwd_supported(bf, D, HID):
+        mo1, ro1 = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+        xn1 = torch.empty_like(xn_out)
+        out1, x_mid1, m21, r21, u1, h1 = K.block_tail_fwd(dev(a_, bf), dev(x_in, bf), dev(wp, bf), dev(bp), dev(g), dev(b),
+                                                          dev(w1, bf), dev(b1), dev(w2, bf), dev(b2), xn_out=xn1, stats=(mo1, ro1))
+        assert rel_err(x_mid.float().cpu(), x_mid1.float().cpu()) < 4e-3      # different summation order, then one rounding
+        assert rel_err(m2.cpu(), m21.cpu()) < 1e-3 and rel_err(r2.cpu(), r21.cpu()) < 1e-3
+        assert rel_err(xn_out.float().cpu(), xn1.float().cpu()) < 8e-3
+        assert rel_err(out.float().cpu(), out1.float().cpu()) < 8e-3
+        assert rel_err(mo.cpu(), mo1.cpu()) < 2e-3 and rel_err(ro.cpu(), ro1.cpu()) < 2e-3
+        if save:
+            assert rel_err(h.float().cpu(), h1.float().cpu()) < 8e-3
+    # fp32 math on the rounded operands, stage by stage from the kernel's own (rounded) intermediates
+    xm = q(a_, "bf16") @ q(wp, "bf16").t() + bp + q(x_in, "bf16")
+    assert rel_err(x_mid.float().cpu(), xm) < BF16_TOL
+    xmq = x_mid.float().cpu()
+    assert rel_err(m2.cpu(), xmq.mean(1)) < 1e-5
+    assert rel_err(r2.cpu(), (xmq.var(1, unbiased=False) + 1e-5).rsqrt()) < 1e-5
+    xn = torch.nn.functional.layer_norm(xmq, (D,), g, b)
+    assert rel_err(xn_out.float().cpu(), xn) < BF16_TOL
+    xnq = xn_out.float().cpu()
+    u_ref = (xnq @ q(w1, "bf16").t() + b1).requires_grad_(True)
+    h_ref = torch.nn.functional.gelu(u_ref)
+    if save:
+        assert rel_err(h.float().cpu(), h_ref.detach()) < 6e-3
+        gp_ref, = torch.autograd.grad(h_ref.sum(), u_ref)
+        assert rel_err(gp.float().cpu(), gp_ref) < 6e-3                       # gelu'(u), one bf16 rounding
+    ref = xmq + q(h_ref.detach(), "bf16") @ q(w2, "bf16").t() + b2
+    assert rel_err(out.float().cpu(), ref) < BF16_TOL
+    o = out.float().cpu()
+    assert rel_err(mo.cpu(), o.mean(1)) < 1e-4
+    assert rel_err(ro.cpu(), (o.var(1, unbiased=False) + 1e-5).rsqrt()) < 1e-4
+
+
+def test_block_tail2_unsupported_shapes_are_errors(K):
+    bf = torch.bfloat16
+    assert not K.block_tail2_supported(bf, 256, 768) and not K.block_tail2_supported(torch.float32, 192, 768)
+    assert not K.block_tail2_supported(bf, 192, 100) and not K.block_tail2_supported(bf, 192, 3072)
+    assert not K.block_tail2_supported(bf, 192, 64)
+
+
 @pytest.mark.parametrize("M", [650, 130 + 77])
 def test_block_tail_backward_equals_mlp_bwd_then_proj_dgrad(K, M):
     D, HID, bf = 192, 768, torch.bfloat16
@@ -311,6 +395,29 @@ def test_block_tail_backward_equals_mlp_bwd_then_proj_dgrad(K, M):
     assert rel_err(dg1.cpu(), dg2.cpu()) < 1e-5 and rel_err(db1.cpu(), db2.cpu()) < 1e-5
     assert rel_err(da.float().cpu(), da2.float().cpu()) < 1e-5
     assert rel_err(da.float().cpu(), dx.float().cpu() @ q(wpt, "bf16").t()) < BF16_TOL
+
+
+def test_block_tail_backward_from_saved_gelu_derivative(K):
+    """vitpe_block_tail_bwd_gp: the backward fed gelu'(u) (what block_tail2_fwd saves) instead of u -- du = (dy W2) * gp
+    exactly, and everything downstream equal to the u-fed launch within the one extra bf16 rounding of gp."""
+    M, D, HID, bf = 650, 192, 768, torch.bfloat16
+    x, g = rnd(M, D, seed=41), 1 + 0.1 * rnd(D, seed=42)
+    dy, u = rnd(M, D, seed=43), rnd(M, HID, seed=44)
+    w2t, w1t, wpt = rnd(HID, D, seed=45, scale=0.05), rnd(D, HID, seed=46, scale=0.08), rnd(D, D, seed=47, scale=0.07)
+    xd = dev(x, bf)
+    _, mean, rstd = K.layernorm_fwd(xd, dev(g), torch.zeros(D, device="cuda"))
+    uq = q(u, "bf16").requires_grad_(True)
+    gp, = torch.autograd.grad(torch.nn.functional.gelu(uq).sum(), uq)
+    dg1, db1 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    dx, du, da = K.block_tail_bwd(dev(dy, bf), dev(u, bf), dev(w2t, bf), dev(w1t, bf), xd, mean, rstd, dev(g), dg1, db1, dev(wpt, bf))
+    dg2, db2 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    dx2, du2, da2 = K.block_tail_bwd(dev(dy, bf), dev(gp, bf), dev(w2t, bf), dev(w1t, bf), xd, mean, rstd, dev(g), dg2, db2,
+                                     dev(wpt, bf), u_is_gprime=True)
+    ref_du = (q(dy, "bf16") @ q(w2t, "bf16").t()) * q(gp, "bf16")
+    assert rel_err(du2.float().cpu(), ref_du) < 6e-3
+    assert rel_err(du2.float().cpu(), du.float().cpu()) < 8e-3
+    assert rel_err(dx2.float().cpu(), dx.float().cpu()) < 8e-3 and rel_err(da2.float().cpu(), da.float().cpu()) < 8e-3
+    assert rel_err(dg2.cpu(), dg1.cpu()) < 5e-3 and rel_err(db2.cpu(), db1.cpu()) < 5e-3
 
 
 def test_fused_mlp_unsupported_is_an_error(K):

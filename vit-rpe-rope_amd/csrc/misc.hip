@@ -659,7 +659,8 @@ __global__ void transpose_cast_kernel(const float* __restrict__ src, T* __restri
 
 // All weight shadows of the model in ONE launch (after the optimizer step): a descriptor per matrix,
 // each workgroup handles one 32x32 tile.  kind 0: dst[c][r] = src[r][c] (transposed shadow for the
-// data-gradient GEMMs); kind 1: fragment-major packing of attn.qkv.weight (see pack_qkv_kernel).
+// data-gradient GEMMs); kind 1: fragment-major packing of attn.qkv.weight (see pack_qkv_kernel); kind 2 / 3: the
+// fragment-major packing of tail2.hip (natural / acc_to_frag k order, HD field = k chunk).
 struct ShadowDesc { long long src_off, dst_off; int R, C, tile0, kind, HD, pad; };
 
 template <typename T>
@@ -685,6 +686,21 @@ __global__ __launch_bounds__(256) void refresh_shadows_kernel(const float* __res
     for (int i = ty; i < 32; i += 8) {
       const int c = c0 + i, r = r0 + tx;
       if (c < ds.C && r < ds.R) dst[(size_t)c * ds.R + r] = from_f32<T>(tile[tx][i]);
+    }
+  } else if (ds.kind >= 2) {
+    // vitpe_pack_weight_frags layout (tail2.hip): HD field = k chunk; kind 2 natural k order, kind 3 acc_to_frag order
+    const int kch = ds.HD, KSC = kch / 32, NTr = ds.R / 16;
+    for (int i = ty; i < 32; i += 8) {
+      const int r = r0 + i, c = c0 + tx;
+      if (r < ds.R && c < ds.C) {
+        const int nt = r / 16, cc = r % 16, kc = c / kch, ks = (c % kch) / 32, k = c % 32;
+        int g, e;
+        if (ds.kind == 2) { g = k / 8; e = k % 8; }
+        else if (k < 16) { g = k / 4; e = k % 4; }
+        else { g = (k - 16) / 4; e = 4 + (k - 16) % 4; }
+        const size_t blk = ((size_t)kc * NTr + nt) * KSC + ks;
+        dst[(blk * 64 + 16 * g + cc) * 8 + e] = from_f32<T>(tile[i][tx]);
+      }
     }
   } else {
     // W[3D, D]: row = mat*D + h*HD + 16nt + cc ; col = 32ks + 8g + e  ->  block (h,mat,nt,ks), lane 16g+cc, e

@@ -61,7 +61,8 @@ struct MlpFwdArgs {
   //   da = dx W_proj  (dx = this kernel's output rows), stored to `post_out` (input of the attention backward)
   const void* post_w;   // attn.proj.weight^T [192,192] T (transposed shadow)
   void* post_out;       // [M,192]
-  const void* u_in;     // MLP_BWD: pre-activation u [M,HID] saved by the forward
+  const void* u_in;     // MLP_BWD: pre-activation u [M,HID] saved by the forward (or gelu'(u), see u_is_gprime)
+  int u_is_gprime;      // MLP_BWD: u_in holds gelu'(u) (saved by vitpe_block_tail2_fwd): multiply, no erf here
   const void* ln_x;     // MLP_BWD: LayerNorm input rows (x_mid) [M,192]
   float* dgamma;        // MLP_BWD: accumulated (fp32 atomics, one per column and workgroup)
   float* dbeta;
@@ -323,7 +324,12 @@ __global__ __launch_bounds__(768) void mlp_fwd_kernel(MlpFwdArgs a) {
             chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(reinterpret_cast<const T*>(a.u_in) + (size_t)min(gm, m_end - 1) * HID + gn), uv);
 #pragma unroll
             for (int t = 0; t < 4; ++t) { v[t] = x0[t]; v[4 + t] = x1[t]; }
-            gelu_erf_grad_mul_x8(v, uv);
+            if (a.u_is_gprime) {
+#pragma unroll
+              for (int t = 0; t < 8; ++t) v[t] *= uv[t];
+            } else {
+              gelu_erf_grad_mul_x8(v, uv);
+            }
             hc = f32_to_chunk<T>(v);
             if (gm < m_end) *reinterpret_cast<Chunk16*>(Uo + (size_t)gm * HID + gn) = hc;
           }
@@ -597,7 +603,7 @@ extern "C" int vitpe_block_tail_fwd(int dtype, const void* attn_out, const void*
 
 // Backward mirror of vitpe_block_tail_fwd's fusion: vitpe_mlp_bwd plus the data gradient of the attention projection,
 //   da = dx W_proj   [M,192]  (WpT = attn.proj.weight^T, the transposed shadow), the input of the attention backward.
-extern "C" int vitpe_block_tail_bwd(int dtype, const void* dy, const void* u, const void* W2t, const void* W1t,
+static int block_tail_bwd_impl(int u_is_gprime, int dtype, const void* dy, const void* u, const void* W2t, const void* W1t,
                                     const void* x, const float* mean, const float* rstd, const float* gamma, void* du,
                                     void* dx, float* dgamma, float* dbeta, const void* WpT, void* da, int M, int D,
                                     int HID, hipStream_t stream) {
@@ -607,5 +613,19 @@ extern "C" int vitpe_block_tail_bwd(int dtype, const void* dy, const void* u, co
   MlpFwdArgs a{};
   a.x = dy; a.gamma = gamma; a.mean = mean; a.rstd = rstd; a.W1 = W2t; a.W2 = W1t; a.u_out = du; a.out = dx;
   a.u_in = u; a.ln_x = x; a.dgamma = dgamma; a.dbeta = dbeta; a.post_w = WpT; a.post_out = da; a.M = M; a.HID = HID;
+  a.u_is_gprime = u_is_gprime;
   return mlp_launch(MLP_BWD, a, stream, true);
+}
+extern "C" int vitpe_block_tail_bwd(int dtype, const void* dy, const void* u, const void* W2t, const void* W1t,
+                                    const void* x, const float* mean, const float* rstd, const float* gamma, void* du,
+                                    void* dx, float* dgamma, float* dbeta, const void* WpT, void* da, int M, int D,
+                                    int HID, hipStream_t stream) {
+  return block_tail_bwd_impl(0, dtype, dy, u, W2t, W1t, x, mean, rstd, gamma, du, dx, dgamma, dbeta, WpT, da, M, D, HID, stream);
+}
+// The same with gp = gelu'(u) [M,HID] in place of u (what vitpe_block_tail2_fwd saves): du = (dy W2) * gp, no erf.
+extern "C" int vitpe_block_tail_bwd_gp(int dtype, const void* dy, const void* gp, const void* W2t, const void* W1t,
+                                       const void* x, const float* mean, const float* rstd, const float* gamma, void* du,
+                                       void* dx, float* dgamma, float* dbeta, const void* WpT, void* da, int M, int D,
+                                       int HID, hipStream_t stream) {
+  return block_tail_bwd_impl(1, dtype, dy, gp, W2t, W1t, x, mean, rstd, gamma, du, dx, dgamma, dbeta, WpT, da, M, D, HID, stream);
 }

@@ -1,0 +1,571 @@
+// Block tail, second generation ("wave per token tile"): the attention projection + residual + LayerNorm2 + the whole
+// MLP branch + residual of a transformer block (reference models/vit.py:91,116-118,122-124; timm Mlp = fc1 -> GELU ->
+// fc2) in one kernel in which the hidden activation NEVER leaves the registers between fc1 and fc2.
+//
+//   x_mid = x_in + a Wp^T + bp ; xn = LayerNorm2(x_mid) ; u = xn W1^T + b1 ; h = gelu(u) ; out = x_mid + h W2^T + b2
+//
+// Mapping: the M token rows are cut into 16-token tiles, a workgroup takes 8 or 9 consecutive tiles, each of its (up to)
+// 9 waves carries ONE tile through the whole chain.  Every product is computed transposed (A = weight rows, B = token
+// rows): an accumulator tile then holds [feature 16nt + 4g + r][token c], i.e. the token on the lane and the FEATURES in
+// the registers -- exactly the layout in which acc_to_frag turns pairs of accumulator tiles into the B operand of the
+// NEXT product, which contracts over those features (common.h).  So LayerNorm2's output feeds fc1 and gelu(fc1) feeds fc2
+// straight from registers: no LDS image of the normalised panel, none of the hidden chunk (the first generation, mlp.hip,
+// parks both: 108 KB, two barriers per 48-row epilogue pass, 63 barriers per workgroup).  The k order acc_to_frag
+// produces inside a 32-feature chunk (t < 4 -> 4g + t, else 16 + 4g + t - 4) is baked into the packed weight copies ("phi"
+// order), so the weight fragments are plain lane-linear 16-B reads.  Biases are the accumulators' initial values.
+//
+// LDS holds only weights, as 1-KB MFMA fragments filled by LDS-DMA (global_load_lds, 16 B per lane: one instruction moves
+// one fragment, no staging registers): three 48-KB buffers; slab p holds fc1's rows of the 64-wide hidden chunk p (24
+// fragments) and fc2's k chunk p - 1 (24 fragments) and is fetched TWO slabs ahead; one barrier per slab (14 per workgroup
+// at HID = 768).  Inside a slab a wave runs two steps of a three-stage software pipeline over 32-wide sub-chunks t:
+//     { fc1 of sub-chunk t + 1 (12 MFMAs)  ||  GELU epilogue of sub-chunk t  ||  fc2 of sub-chunk t - 1 (12 MFMAs) }
+// the three are independent, so their instructions are interleaved in one scheduling region (an MFMA, its weight
+// fragment read, a slice of the epilogue's VALU work): the matrix pipe runs under the VALU-bound GELU instead of all
+// waves of a SIMD alternating between an MFMA phase and a VALU phase in lock step behind the slab barriers.
+//
+// What training keeps of the hidden layer is h = gelu(u) (fc2's weight gradient) and g' = gelu'(u) (the backward's
+// du = (dy W2) * g'): the derivative costs one more FMA here (Phi(u) and exp(-u^2/2) are already at hand) and saves the
+// backward kernel the whole erf evaluation.  Inference (SAVE = false) writes nothing of the hidden layer.
+// Row statistics (LayerNorm2, and the next block's LayerNorm1 on the output) are in-lane sums over the 48 accumulator
+// values of a token plus two v_permlane swaps.  Rows past M in the last tile are computed as copies of row M - 1 (clamped
+// row index for loads AND stores: identical values written to the same address), so there is no guarded path.
+#include "common.h"
+
+#ifndef T2_NT_HID
+#define T2_NT_HID true
+#endif
+#ifndef T2_NV
+#define T2_NV 8
+#endif
+
+namespace vitpe {
+
+struct Tail2Args {
+  const void* a;        // [M,192] merged-head attention output
+  const void* xin;      // [M,192] block input (residual)
+  const void* wp;       // attn.proj.weight packed (kchunk 192, natural order)
+  const float* bp;
+  const float* gamma;   // norm2
+  const float* beta;
+  const void* w1;       // mlp.fc1.weight packed (kchunk 192, phi order)
+  const float* b1;
+  const void* w2;       // mlp.fc2.weight packed (kchunk 32, phi order)
+  const float* b2;
+  void* xmid;           // [M,192] out
+  float* mean2;         // [M] LayerNorm2 statistics of x_mid, out
+  float* rstd2;
+  void* xn_out;         // [M,192] LayerNorm2(x_mid), nullable
+  void* gp_out;         // [M,HID] gelu'(u)   (SAVE only)
+  void* h_out;          // [M,HID] gelu(u)    (SAVE only)
+  void* out;            // [M,192]
+  float* mean_out;      // statistics of the output rows (next norm1), nullable (both or neither)
+  float* rstd_out;
+  int M, HID;
+  float eps2, eps_next;
+  unsigned long long* census;   // CENSUS instantiation only (include/vitpe_debug.h)
+};
+
+constexpr int T2_D = 192, T2_NT = 12, T2_KS = 6, T2_WAVES = 9;   // compute waves per workgroup
+constexpr int T2_THREADS = 64 * (T2_WAVES + 2);                      // + two loader waves
+constexpr int T2_MAXHID = 1536, T2_NFLAG = T2_MAXHID / 64 + 2;
+constexpr int T2_CH = 64, T2_CNT = T2_CH / 16, T2_CKS = T2_CH / 32;   // hidden chunk per slab: output tiles of fc1, k steps of fc2
+constexpr int T2_HALF = T2_CNT * T2_KS;                               // 24 fragments of fc1, 24 of fc2 (12 x 2) per slab
+constexpr int T2_SLABF = 2 * T2_HALF;                                 // fragments per slab buffer
+static_assert(T2_NT * T2_CKS == T2_HALF, "slab halves");
+
+// lanes c, c+16, c+32, c+48 hold different features of the same token: sum across the four groups
+VITPE_DEV float t2_xg_sum(float v) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
+// 16-B store of a tile pair: lane (c, g) holds features 16nt + 4g + r (r < 4) of token c for two adjacent tiles; one
+// v_permlane16_swap per dword gives every lane 8 CONTIGUOUS features (see attn.hip)
+template <bool NONTEMPORAL>
+VITPE_DEV void t2_store_pair(bf16* rowp, int nt0, int g, const f32x4& o0, const f32x4& o1) {
+  uint32_t lo[2], hi[2];
+#pragma unroll
+  for (int w2 = 0; w2 < 2; ++w2) {
+    bf16x2 pa, pb;
+    pa[0] = (bf16)o0[2 * w2]; pa[1] = (bf16)o0[2 * w2 + 1];
+    pb[0] = (bf16)o1[2 * w2]; pb[1] = (bf16)o1[2 * w2 + 1];
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, pa), __builtin_bit_cast(uint32_t, pb), false, false);
+    lo[w2] = r[0]; hi[w2] = r[1];
+  }
+  const int f0 = 16 * (nt0 + (g & 1)) + 8 * (g >> 1);
+  const Chunk16 v = {lo[0], lo[1], hi[0], hi[1]};
+  if (NONTEMPORAL) __builtin_nontemporal_store(v, reinterpret_cast<Chunk16*>(rowp + f0));
+  else *reinterpret_cast<Chunk16*>(rowp + f0) = v;
+}
+
+// acc[nt] += sum_ks W(nt, ks) x bf[ks] over NTL x KSL weight fragments in LDS (fragment (nt, ks) at wb + (nt * KSL + ks) * 512
+// elements, wb already lane-offset), k step outer / output tile inner so consecutive MFMAs hit different accumulators.
+// Software pipelined by hand as a ring of R fragment registers: the ds_read of fragment q + R - 1 is issued right before
+// the MFMA of fragment q, so every read has R - 1 MFMAs to land.  (Left alone the compiler reads one fragment ahead and
+// waits lgkmcnt(1) before every MFMA.)  t2_gemm_code emits the instructions, t2_gemm_order pins their order with NV VALU
+// instructions of whatever else is in the scheduling region after every MFMA.
+template <int NTL, int KSL, int R>
+VITPE_DEV void t2_gemm_code(const bf16* wb, const Frag<bf16>* bf, f32x4* acc) {
+  constexpr int TOT = NTL * KSL;
+  static_assert(TOT >= R, "ring deeper than the product");
+  Frag<bf16> w[R];
+#pragma unroll
+  for (int i = 0; i < R - 1; ++i) w[i] = ld_frag(wb + ((i % NTL) * KSL + i / NTL) * 512);
+#pragma unroll
+  for (int q = 0; q < TOT; ++q) {
+    if (q + R - 1 < TOT) {
+      const int n = q + R - 1;
+      w[n % R] = ld_frag(wb + ((n % NTL) * KSL + n / NTL) * 512);
+    }
+    mma(w[q % R], bf[q / NTL], acc[q % NTL]);
+  }
+}
+template <int TOT, int R, int NV>
+VITPE_DEV void t2_gemm_order() {
+  __builtin_amdgcn_sched_group_barrier(0x100, R - 1, 0);
+#pragma unroll
+  for (int q = 0; q < TOT; ++q) {
+    if (q + R - 1 < TOT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // one MFMA
+    if (NV > 0) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);           // NV VALU instructions
+  }
+}
+template <int NTL, int KSL, int R>
+VITPE_DEV void t2_gemm(const bf16* wb, const Frag<bf16>* bf, f32x4* acc) {
+  __builtin_amdgcn_sched_barrier(0);
+  t2_gemm_code<NTL, KSL, R>(wb, bf, acc);
+  t2_gemm_order<NTL * KSL, R, 0>();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// h = gelu(x) = x Phi(x) and g = gelu'(x) = Phi(x) + x phi(x), exact-erf form (nn.GELU default, reference vit.py:111), in 15
+// VALU + 2 transcendental instructions.  Same Abramowitz-Stegun 7.1.26 erfc as common.h's gelu_cdf (|err| <= 1.5e-7) with
+// everything foldable folded:  T = 1 / (1 + p|x|/sqrt2);  E = phi(x) = exp2(-x^2 log2(e)/2 + log2(1/sqrt(2 pi)));
+// H = erfc(|x|/sqrt2)/2 = E * T * poly(T) with the coefficients pre-divided by 2 phi(0);
+// h = max(x, 0) - |x| H   (x >= 0: x (1 - H); x < 0: x H);   r = |x| E - H;   g = x >= 0 ? 1 + r : -r.
+// Checked against float64 erf over [-8, 8]: |h - ref| <= 3.3e-7, |g - ref| <= 2.6e-7.
+VITPE_DEV void t2_gelu(float x, float& h, float& g) {
+  constexpr float C = 0.39894228040143267794f;               // phi(0) = 1 / sqrt(2 pi)
+  const float ax = fabsf(x);
+  const float T = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752440f, 1.0f));
+  float q = fmaf(T, 1.061405429f / (2.f * C), -1.453152027f / (2.f * C));
+  q = fmaf(T, q, 1.421413741f / (2.f * C));
+  q = fmaf(T, q, -0.284496736f / (2.f * C));
+  q = fmaf(T, q, 0.254829592f / (2.f * C));
+  const float E = __builtin_amdgcn_exp2f(fmaf(x * x, -0.72134752044448170368f, -1.32574806473615827f));
+  const float H = (q * T) * E;
+  h = fmaf(-ax, H, fmaxf(x, 0.f));
+  const float r = fmaf(ax, E, -H);
+  g = x >= 0.f ? 1.0f + r : -r;
+}
+
+// One step of the three-stage pipeline over 32-wide hidden sub-chunks t:
+//   F1: fc1 product of sub-chunk t + 1  (12 MFMAs: 2 output tiles x 6 k steps, B = the LayerNorm2 fragments)  -> a1n
+//   G : GELU epilogue of sub-chunk t    (a1c = u with bias -> h fragment hnew; SAVE: h and g' rows stored)
+//   F2: fc2 product of sub-chunk t - 1  (12 MFMAs: 12 output tiles x 1 k step, B = hprev)                      -> acc2
+// The three are independent, so they go into ONE scheduling region: the two products' fragments alternate through one
+// ring of R registers and every MFMA is followed by NV VALU instructions of the epilogue.
+// w1f / w2f: lane-offset LDS pointers to the sub-chunk's fragments (fc1: (tile * 6 + k step) * 512, fc2: tile * 512).
+template <bool F1, bool G, bool F2, bool SAVE, int EXP = 0>
+VITPE_DEV void t2_substep(const bf16* w1f, const bf16* w2f, const Frag<bf16> (&bf)[T2_KS], f32x4 (&a1n)[2],
+                          const f32x4 (&a1c)[2], const Frag<bf16>& hprev, Frag<bf16>& hnew, f32x4 (&acc2)[T2_NT],
+                          bf16* gpr, bf16* hr, int g) {
+  constexpr int R = 8, TOT = (F1 ? 12 : 0) + (F2 ? 12 : 0), NV = (F1 && F2) ? T2_NV : 2 * T2_NV;
+  __builtin_amdgcn_sched_barrier(0);
+  if (TOT > 0) {
+    // unified fragment list: both products -> even q = fc2 fragment q / 2, odd q = fc1 fragment q / 2
+    auto frag_ptr = [&](int q) -> const bf16* {
+      const bool is2 = (F1 && F2) ? (q % 2 == 0) : F2;
+      const int j = (F1 && F2) ? q / 2 : q;
+      return is2 ? w2f + j * 512 : w1f + ((j % 2) * T2_KS + j / 2) * 512;     // fc1: k step outer, tile inner
+    };
+    Frag<bf16> w[R];
+#pragma unroll
+    for (int i = 0; i < R - 1; ++i) w[i] = ld_frag(frag_ptr((EXP & 1) ? (i & ~3) : i));
+#pragma unroll
+    for (int q = 0; q < TOT; ++q) {
+      if (q + R - 1 < TOT) w[(q + R - 1) % R] = ld_frag(frag_ptr((EXP & 1) ? ((q + R - 1) & ~3) : q + R - 1));
+      const bool is2 = (F1 && F2) ? (q % 2 == 0) : F2;
+      const int j = (F1 && F2) ? q / 2 : q;
+      if (is2) mma(w[q % R], hprev, acc2[j]);
+      else mma(w[q % R], bf[j / 2], a1n[j % 2]);
+    }
+  }
+  if (G) {
+    // scalar fp32 on purpose: packed f32 VALU (v_pk_mul/fma_f32) issues several times slower than two scalar
+    // instructions beside MFMAs on gfx950 (MI355X_MICROARCH.md, issue-cost table), and this epilogue IS the bound
+    f32x4 gp[2], hh[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float x = a1c[q][t];
+        if (EXP & 2) { hh[q][t] = 0.5f * x; gp[q][t] = x; continue; }
+        float hv, gv;
+        t2_gelu(x, hv, gv);
+        hh[q][t] = hv;
+        gp[q][t] = gv;
+      }
+    }
+    if (SAVE && !(EXP & 4)) {
+      t2_store_pair<T2_NT_HID>(gpr, 0, g, gp[0], gp[1]);      // read again only in backward
+      t2_store_pair<T2_NT_HID>(hr, 0, g, hh[0], hh[1]);
+    }
+    hnew = acc_to_frag<bf16>(hh[0], hh[1]);
+  }
+  if (TOT > 0) {
+    __builtin_amdgcn_sched_group_barrier(0x100, R - 1, 0);
+#pragma unroll
+    for (int q = 0; q < TOT; ++q) {
+      if (q + R - 1 < TOT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // one MFMA
+      if (G) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);                // NV VALU instructions of the epilogue
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool SAVE, bool CENSUS, int EXP = 0>
+__global__ __launch_bounds__(T2_THREADS) void block_tail2_fwd_kernel(Tail2Args a) {
+  using T = bf16;
+  constexpr int D = T2_D, NT = T2_NT, KS = T2_KS;
+  __shared__ __attribute__((aligned(16))) T sW[3 * T2_SLABF * 512];
+  __shared__ __attribute__((aligned(16))) float sPar[4 * T2_D + T2_MAXHID];   // bp | gamma | beta | b2 | b1
+  __shared__ int sReady[T2_NFLAG], sDone[T2_NFLAG];   // loader <-> compute handshakes (see below)
+
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int HID = a.HID, nchunk = HID / T2_CH;
+  // tiles of this workgroup / wave
+  const int ntiles = (a.M + 15) / 16, base = ntiles / (int)gridDim.x, rem = ntiles % (int)gridDim.x;
+  const int tile0 = (int)blockIdx.x * base + min((int)blockIdx.x, rem), ntile_wg = base + ((int)blockIdx.x < rem ? 1 : 0);
+  const bool active = wave < ntile_wg;                        // wave-uniform
+  const int rowc = min(16 * (tile0 + wave) + c, a.M - 1);    // rows past M: copies of row M - 1
+
+  unsigned long long acc_sync = 0, acc_fc1 = 0, acc_mix = 0, tm0 = 0;
+  auto now = [&]() -> unsigned long long { return CENSUS ? __builtin_amdgcn_s_memtime() : 0ull; };
+  auto stamp = [&](int slot) {
+    if (CENSUS && lane == 0 && wave < T2_WAVES) a.census[((size_t)blockIdx.x * T2_WAVES + wave) * 16 + slot] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
+  auto dma1 = [&](const T* src_frag, int dst_frag) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_frag + lane * 8),
+                                     (__attribute__((address_space(3))) void*)(sW + dst_frag * 512), 16, 0, 0);
+  };
+  // Wp -> fragments [0, 72): every wave issues its share (the first product waits for these)
+#pragma unroll
+  for (int i = 0; i < (NT * KS + T2_THREADS / 64 - 1) / (T2_THREADS / 64); ++i) {
+    const int f = wave + (T2_THREADS / 64) * i;
+    if (f < NT * KS) dma1(reinterpret_cast<const T*>(a.wp) + (size_t)f * 512, f);
+  }
+  if (threadIdx.x < T2_NFLAG) { sReady[threadIdx.x] = 0; sDone[threadIdx.x] = 0; }
+  for (int i = threadIdx.x; i < 4 * D + HID; i += T2_THREADS) {     // parameters -> LDS
+    const int k = i / D;
+    sPar[i] = k == 0 ? a.bp[i] : k == 1 ? a.gamma[i - D] : k == 2 ? a.beta[i - 2 * D] : k == 3 ? a.b2[i - 3 * D] : a.b1[i - 4 * D];
+  }
+
+  // ---- waves 9 and 10: the loaders.  All further weight traffic of the workgroup is their LDS-DMA (an LDS-DMA piece costs
+  // its issuing wave ~100 cycles of issue -- MI355X_MICROARCH.md, and measured here: one loader sustains a 48-piece slab
+  // per 4.9 K cycles, which is why there are two; spread over the compute waves the pieces cost ~1 K cycles per wave and
+  // slab right behind every barrier), and only THEY wait on vmcnt: the compute waves never wait for their own stores.
+  // Wave 9 moves the fc1 halves of slabs 0 .. nchunk - 1, wave 10 the fc2 halves of slabs 1 .. nchunk, 24 pieces each.
+  // After the one barrier that publishes Wp and the parameters there are NO workgroup barriers: a loader counts itself
+  // into sReady[s] when its half of slab s has landed, a compute wave counts itself into sDone[] when it has consumed a
+  // slab (sDone[0]: the proj fragments, sDone[s + 1]: slab s), and a loader refills a buffer when all active waves have
+  // left it.  The compute waves never wait for each other, so the waves of a SIMD drift apart and one's MFMAs run under
+  // another's GELU.
+  if (wave >= T2_WAVES) {
+    const bool is1 = wave == T2_WAVES;                 // fc1 halves : fc2 halves
+    const int first = is1 ? 0 : 1, last = is1 ? nchunk - 1 : nchunk;
+    const T* const src = is1 ? reinterpret_cast<const T*>(a.w1) : reinterpret_cast<const T*>(a.w2) - (size_t)T2_HALF * 512;
+    const int half = is1 ? 0 : T2_HALF;
+    auto dma_half = [&](int sl) {                      // this loader's half of slab sl -> buffer (sl + 2) % 3
+      const int b0 = ((sl + 2) % 3) * T2_SLABF + half;
+#pragma unroll
+      for (int f = 0; f < T2_HALF; ++f) dma1(src + ((size_t)sl * T2_HALF + f) * 512, b0 + f);
+    };
+    auto wait_done = [&](int k) {     // all active compute waves have counted themselves into sDone[k]
+      while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sDone[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < ntile_wg) __builtin_amdgcn_s_sleep(2);
+      asm volatile("" ::: "memory");
+    };
+    auto raise = [&](int sl) {
+      asm volatile("" ::: "memory");
+      if (lane == 0) atomicAdd(&sReady[sl], 1);
+    };
+    __builtin_amdgcn_s_waitcnt(0x0070);         // vmcnt(0) lgkmcnt(0): this wave's Wp pieces, LDS parameter stores
+    asm volatile("s_barrier" ::: "memory");     // the one barrier
+    if (is1) {
+      dma_half(0);                        // -> buffer 2 (not under Wp)
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      raise(0);
+    }
+    wait_done(0);                         // everyone past the proj product: its fragments may be overwritten
+    dma_half(1);
+    if (2 <= last) dma_half(2);
+    for (int sl = 1; sl <= last; ++sl) {
+      // slab sl must have landed; the only pieces issued after it are slab sl + 1's
+      if (sl + 1 <= last) __builtin_amdgcn_s_waitcnt(0x4F78);   // vmcnt(24)
+      else __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+      raise(sl);
+      if (sl + 2 <= last) {
+        wait_done(sl);                    // sDone[sl] counts slab sl - 1: its buffer is the one slab sl + 2 goes to
+        dma_half(sl + 2);
+      }
+    }
+    return;
+  }
+  auto wait_ready = [&](int sl) {       // both halves of slab sl (one for the first and the last slab) have landed
+    const int need = (sl < nchunk ? 1 : 0) + (sl >= 1 ? 1 : 0);
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sReady[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+  };
+  auto signal_done = [&](int k) {       // this wave's LDS reads of the buffer are complete (consumed by MFMAs)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) atomicAdd(&sDone[k], 1);
+  };
+
+  // ---- compute waves: this wave's tokens as B fragments (natural k order), straight from global ---------------------------
+  Frag<T> bf[KS];
+  if (active) {
+    const T* ar = reinterpret_cast<const T*>(a.a) + (size_t)rowc * D + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bf[ks] = ld_frag(ar + 32 * ks);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0070);           // vmcnt(0) lgkmcnt(0): Wp pieces, token fragments, LDS parameter stores
+  asm volatile("s_barrier" ::: "memory");       // the one barrier
+  if (!active) return;
+  stamp(1);
+  // the residual rows: issued now (no LDS-DMA of this wave is in flight any more, so the compiler's own vmcnt waits are
+  // counted ones again) and landing under the first product
+  bf16x4 xres[NT];
+  {
+    const T* xr = reinterpret_cast<const T*>(a.xin) + (size_t)rowc * D + 4 * g;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) xres[nt] = *reinterpret_cast<const bf16x4*>(xr + 16 * nt);
+  }
+
+  // ---- x_mid = x_in + proj + bias; LayerNorm2 statistics; xn -> B fragments of fc1 --------------------------------------
+  T* const xmr = reinterpret_cast<T*>(a.xmid) + (size_t)rowc * D;
+  const float invD = 1.0f / (float)D;
+  {
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = *reinterpret_cast<const f32x4*>(sPar + 16 * nt + 4 * g);
+    t2_gemm<NT, KS, 12>(sW + lane * 8, bf, acc);
+    signal_done(0);
+    stamp(2);
+    float s1 = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { acc[nt][r] = to_f32(from_f32<T>(acc[nt][r] + (float)xres[nt][r])); s1 += acc[nt][r]; }   // values as stored
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; nt += 2) t2_store_pair<false>(xmr, nt, g, acc[nt], acc[nt + 1]);
+    const float mean = t2_xg_sum(s1) * invD;
+    float s2 = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float d = acc[nt][r] - mean; s2 += d * d; }
+    const float rstd = 1.0f / sqrtf(t2_xg_sum(s2) * invD + a.eps2);
+    if (g == 0) { a.mean2[rowc] = mean; a.rstd2[rowc] = rstd; }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      __builtin_amdgcn_sched_barrier(0);
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(sPar + D + 16 * nt + 4 * g);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(sPar + 2 * D + 16 * nt + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[nt][r] = fmaf((acc[nt][r] - mean) * rstd, gv[r], bv[r]);
+    }
+    if (a.xn_out != nullptr) {
+      T* xnr = reinterpret_cast<T*>(a.xn_out) + (size_t)rowc * D;
+#pragma unroll
+      for (int nt = 0; nt < NT; nt += 2) t2_store_pair<true>(xnr, nt, g, acc[nt], acc[nt + 1]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bf[ks] = acc_to_frag<T>(acc[2 * ks], acc[2 * ks + 1]);   // phi order inside the chunk
+  }
+
+  // ---- the MLP branch: slab p = fc1 rows of the 64-wide chunk p | fc2 k chunk p - 1, two pipeline steps per slab ----------
+  f32x4 acc2[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc2[nt] = *reinterpret_cast<const f32x4*>(sPar + 3 * D + 16 * nt + 4 * g);   // b2
+  T* const gpr = SAVE ? reinterpret_cast<T*>(a.gp_out) + (size_t)rowc * HID : nullptr;
+  T* const hr = SAVE ? reinterpret_cast<T*>(a.h_out) + (size_t)rowc * HID : nullptr;
+  f32x4 aX[2], aY[2];          // fc1 accumulators of the even / odd 32-wide sub-chunk in flight
+  Frag<T> hP, hQ;              // gelu fragments of the even / odd sub-chunk in flight
+  const float* const b1l = sPar + 4 * D + 4 * g;
+  auto bias1 = [&](f32x4 (&acc1)[2], int t) {     // fc1 bias of sub-chunk t = the accumulators' initial value
+    acc1[0] = *reinterpret_cast<const f32x4*>(b1l + 32 * t);
+    acc1[1] = *reinterpret_cast<const f32x4*>(b1l + 32 * t + 16);
+  };
+
+  stamp(3);
+  wait_ready(0);
+  stamp(4);
+  {
+    const T* wb = sW + 2 * T2_SLABF * 512 + lane * 8;
+    bias1(aX, 0);
+    t2_substep<true, false, false, SAVE, EXP>(wb, wb, bf, aX, aY, hQ, hQ, acc2, gpr, hr, g);                           // F1_0
+    bias1(aY, 1);
+    t2_substep<true, true, false, SAVE, EXP>(wb + 2 * KS * 512, wb, bf, aY, aX, hQ, hP, acc2, gpr, hr, g);             // F1_1 G_0
+    signal_done(1);
+  }
+  stamp(5);
+  for (int p = 1; p < nchunk; ++p) {
+    if (CENSUS) tm0 = now();
+    wait_ready(p);
+    if (CENSUS) { const unsigned long long t = now(); acc_sync += t - tm0; tm0 = t; }
+    {
+      const T* wb = sW + ((p + 2) % 3) * T2_SLABF * 512 + lane * 8;
+      const T* w2b = wb + T2_HALF * 512;
+      bias1(aX, 2 * p);
+      t2_substep<true, true, true, SAVE, EXP>(wb, w2b, bf, aX, aY, hP, hQ, acc2, gpr + 32 * (2 * p - 1), hr + 32 * (2 * p - 1), g);
+      if (CENSUS) { const unsigned long long t = now(); acc_fc1 += t - tm0; tm0 = t; }
+      bias1(aY, 2 * p + 1);
+      t2_substep<true, true, true, SAVE, EXP>(wb + 2 * KS * 512, w2b + NT * 512, bf, aY, aX, hQ, hP, acc2, gpr + 32 * (2 * p),
+                                         hr + 32 * (2 * p), g);
+      signal_done(p + 1);
+      if (CENSUS) acc_mix += now() - tm0;
+    }
+  }
+  stamp(6);
+  wait_ready(nchunk);
+  stamp(7);
+  if (CENSUS && lane == 0) {
+    unsigned long long* cz = a.census + ((size_t)blockIdx.x * T2_WAVES + wave) * 16;
+    cz[10] = acc_sync; cz[11] = acc_fc1; cz[12] = acc_mix;
+  }
+  {
+    const T* w2b = sW + ((nchunk + 2) % 3) * T2_SLABF * 512 + T2_HALF * 512 + lane * 8;
+    const int tl = 2 * nchunk - 1;
+    t2_substep<false, true, true, SAVE, EXP>(w2b, w2b, bf, aX, aY, hP, hQ, acc2, gpr + 32 * tl, hr + 32 * tl, g);        // G_last F2
+    t2_substep<false, false, true, SAVE, EXP>(w2b, w2b + NT * 512, bf, aX, aY, hQ, hQ, acc2, gpr, hr, g);               // F2_last
+  }
+  stamp(8);
+
+  // ---- out = x_mid + fc2 + bias; statistics for the next block's LayerNorm1 ----------------------------------------------
+  {
+    T* const outr = reinterpret_cast<T*>(a.out) + (size_t)rowc * D;
+    float s1 = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const f32x4 rv = ld4(xmr + 16 * nt + 4 * g);     // (this lane's own earlier stores: same wave, same addresses)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { acc2[nt][r] = to_f32(from_f32<T>(acc2[nt][r] + rv[r])); s1 += acc2[nt][r]; }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; nt += 2) t2_store_pair<false>(outr, nt, g, acc2[nt], acc2[nt + 1]);
+    if (a.mean_out != nullptr) {
+      const float mean = t2_xg_sum(s1) * invD;
+      float s2 = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float d = acc2[nt][r] - mean; s2 += d * d; }
+      const float var = t2_xg_sum(s2) * invD;
+      if (g == 0) { a.mean_out[rowc] = mean; a.rstd_out[rowc] = 1.0f / sqrtf(var + a.eps_next); }
+    }
+  }
+  stamp(9);
+}
+
+// Fragment-major packed copy of a weight matrix W [R, C] (R % 16 == 0, C % kchunk == 0, kchunk % 32 == 0) for the kernel
+// above: block (kc, nt, ks) = 64 lanes x 8 elements at index ((kc * R/16 + nt) * KSC + ks), kc = kchunk-wide k chunk,
+// KSC = kchunk / 32, ks = 32-deep step inside it; lane l = 16g + cc, element e  <-  W[16nt + cc][kchunk kc + 32ks + k(g, e)]
+//   natural: k = 8g + e            phi: k = e < 4 ? 4g + e : 16 + 4g + e - 4   (the acc_to_frag order)
+template <typename T>
+__global__ void pack_frags_kernel(const float* __restrict__ w, T* __restrict__ dst, int R, int Cc, int kchunk, int phi) {
+  const long long total = (long long)R * Cc;
+  const int NTr = R / 16, KSC = kchunk / 32;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int e = (int)(idx & 7), l = (int)((idx >> 3) & 63);
+    long long blk = idx >> 9;
+    const int ks = (int)(blk % KSC); blk /= KSC;
+    const int nt = (int)(blk % NTr);
+    const int kc = (int)(blk / NTr);
+    const int cc = l & 15, g = l >> 4;
+    const int k = phi ? (e < 4 ? 4 * g + e : 16 + 4 * g + e - 4) : 8 * g + e;
+    dst[idx] = from_f32<T>(w[(size_t)(16 * nt + cc) * Cc + (size_t)kchunk * kc + 32 * ks + k]);
+  }
+}
+
+}  // namespace vitpe
+
+using namespace vitpe;
+
+extern "C" int vitpe_pack_weight_frags(int dtype, const float* w, void* packed, int R, int C, int kchunk, int phi,
+                                       hipStream_t stream) {
+  VITPE_REQUIRE(w && packed && R > 0 && C > 0 && kchunk > 0 && R % 16 == 0 && kchunk % 32 == 0 && C % kchunk == 0 &&
+                (dtype == 0 || dtype == 1));
+  const long long total = (long long)R * C;
+  const unsigned blocks = (unsigned)min((total + 255) / 256, (long long)2048);
+  if (dtype == 1) hipLaunchKernelGGL(pack_frags_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, w, (bf16*)packed, R, C, kchunk, phi);
+  else hipLaunchKernelGGL(pack_frags_kernel<float>, dim3(blocks), dim3(256), 0, stream, w, (float*)packed, R, C, kchunk, phi);
+  VITPE_CHECK_LAUNCH();
+}
+
+extern "C" int vitpe_block_tail2_supported(int dtype, int D, int HID) {
+  return dtype == 1 && D == T2_D && HID >= 2 * T2_CH && HID % T2_CH == 0 && HID <= T2_MAXHID;
+}
+
+// As vitpe_block_tail_fwd, with the three weights given as vitpe_pack_weight_frags copies: Wp (kchunk 192, natural),
+// W1 (kchunk 192, phi), W2 (kchunk 32, phi); gp_out = gelu'(u) instead of u.  gp_out and h_out: both or neither.
+static int tail2_launch(int dtype, const void* attn_out, const void* x_in, const void* Wp_packed, const float* bp,
+                        const float* gamma, const float* beta, void* x_mid, float* mean2, float* rstd2,
+                        void* xn_out, const void* W1_packed, const float* b1, const void* W2_packed,
+                        const float* b2, void* gp_out, void* h_out, void* out, float* mean_out, float* rstd_out,
+                        float eps2, float eps_next, int M, int D, int HID, unsigned long long* census, int exp, hipStream_t stream) {
+  VITPE_REQUIRE(attn_out && x_in && Wp_packed && bp && gamma && beta && x_mid && mean2 && rstd2 && W1_packed && b1 &&
+                W2_packed && b2 && out && M >= 0);
+  VITPE_REQUIRE((mean_out == nullptr) == (rstd_out == nullptr) && (gp_out == nullptr) == (h_out == nullptr));
+  if (!vitpe_block_tail2_supported(dtype, D, HID)) return (int)hipErrorNotSupported;
+  if (M == 0) return 0;
+  Tail2Args a{};
+  a.a = attn_out; a.xin = x_in; a.wp = Wp_packed; a.bp = bp; a.gamma = gamma; a.beta = beta; a.w1 = W1_packed; a.b1 = b1;
+  a.w2 = W2_packed; a.b2 = b2; a.xmid = x_mid; a.mean2 = mean2; a.rstd2 = rstd2; a.xn_out = xn_out; a.gp_out = gp_out;
+  a.h_out = h_out; a.out = out; a.mean_out = mean_out; a.rstd_out = rstd_out; a.M = M; a.HID = HID; a.eps2 = eps2;
+  a.eps_next = eps_next;
+  // 16-token tiles over workgroups of <= 9 waves: as many workgroups as CUs (x rounds), 8 tiles each where that fits
+  const int ntiles = (M + 15) / 16;
+  int grid;
+  if (ntiles <= 256 * 8) grid = (ntiles + 7) / 8;
+  else grid = 256 * ((ntiles + 256 * T2_WAVES - 1) / (256 * T2_WAVES));
+  a.census = census;
+  if (census != nullptr) {
+    VITPE_REQUIRE(gp_out != nullptr);
+    if (exp == 1) hipLaunchKernelGGL((block_tail2_fwd_kernel<true, true, 1>), dim3(grid), dim3(T2_THREADS), 0, stream, a);
+    else if (exp == 2) hipLaunchKernelGGL((block_tail2_fwd_kernel<true, true, 2>), dim3(grid), dim3(T2_THREADS), 0, stream, a);
+    else if (exp == 4) hipLaunchKernelGGL((block_tail2_fwd_kernel<true, true, 4>), dim3(grid), dim3(T2_THREADS), 0, stream, a);
+    else if (exp == 7) hipLaunchKernelGGL((block_tail2_fwd_kernel<true, true, 7>), dim3(grid), dim3(T2_THREADS), 0, stream, a);
+    else hipLaunchKernelGGL((block_tail2_fwd_kernel<true, true>), dim3(grid), dim3(T2_THREADS), 0, stream, a);
+  } else if (gp_out != nullptr) {
+    hipLaunchKernelGGL((block_tail2_fwd_kernel<true, false>), dim3(grid), dim3(T2_THREADS), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL((block_tail2_fwd_kernel<false, false>), dim3(grid), dim3(T2_THREADS), 0, stream, a);
+  }
+  VITPE_CHECK_LAUNCH();
+}
+
+extern "C" int vitpe_block_tail2_fwd(int dtype, const void* attn_out, const void* x_in, const void* Wp_packed, const float* bp,
+                                     const float* gamma, const float* beta, void* x_mid, float* mean2, float* rstd2,
+                                     void* xn_out, const void* W1_packed, const float* b1, const void* W2_packed,
+                                     const float* b2, void* gp_out, void* h_out, void* out, float* mean_out, float* rstd_out,
+                                     float eps2, float eps_next, int M, int D, int HID, hipStream_t stream) {
+  return tail2_launch(dtype, attn_out, x_in, Wp_packed, bp, gamma, beta, x_mid, mean2, rstd2, xn_out, W1_packed, b1, W2_packed,
+                      b2, gp_out, h_out, out, mean_out, rstd_out, eps2, eps_next, M, D, HID, nullptr, 0, stream);
+}
+
+// debug (include/vitpe_debug.h): the training instantiation with s_memtime stamps, census[(workgroup * 9 + wave) * 16 + slot]
+extern "C" int vitpe_debug_tail2_census(const void* attn_out, const void* x_in, const void* Wp_packed, const float* bp,
+                                        const float* gamma, const float* beta, void* x_mid, float* mean2, float* rstd2,
+                                        void* xn_out, const void* W1_packed, const float* b1, const void* W2_packed,
+                                        const float* b2, void* gp_out, void* h_out, void* out, float* mean_out,
+                                        float* rstd_out, int M, int HID, unsigned long long* census, int exp, hipStream_t stream) {
+  VITPE_REQUIRE(census != nullptr);
+  return tail2_launch(1, attn_out, x_in, Wp_packed, bp, gamma, beta, x_mid, mean2, rstd2, xn_out, W1_packed, b1, W2_packed, b2,
+                      gp_out, h_out, out, mean_out, rstd_out, 1e-5f, 1e-5f, M, T2_D, HID, census, exp, stream);
+}

@@ -77,6 +77,10 @@ class TrainEngine:
             raise L.VitpeError(f"no attention kernel for N={self.N}, D={self.D}, hd={self.D // self.H}")
         if not self.attn_fused:   # the LayerNorm / MLP fusions hang off the fused attention kernels' geometry
             self.fuse_ln = self.fuse_ln_bwd = self.fuse_mlp = False
+        # second-generation block-tail forward (a wave per 16-token tile, hidden activation in registers, weights as
+        # fragment-packed shadows, gelu'(u) saved instead of u); VITPE_TAIL2=0 keeps the first generation
+        self.tail2 = (self.fuse_mlp and self.fuse_ln_bwd and self.fuse_tail and os.environ.get("VITPE_TAIL2", "1") == "1"
+                      and K.block_tail2_supported(self.T, self.D, self.hid))
         self._build_flat(lr, weight_decay, betas, eps)
         self._build_buffers()
         # gradient exchange in two buckets so the first overlaps the lower half of the backward pass:
@@ -114,6 +118,7 @@ class TrainEngine:
         # weights (attention kernels): one flat buffer, refreshed by ONE batched kernel per step
         self._st: Dict[int, torch.Tensor] = {}
         self._pk: Dict[int, torch.Tensor] = {}
+        self._fr: Dict[int, torch.Tensor] = {}
         self._gemm_weights: List[nn.Parameter] = []
         recs, off, tile0 = [], 0, 0
         def add(w, kind):
@@ -124,6 +129,10 @@ class TrainEngine:
             off += (R * C + ALIGN - 1) // ALIGN * ALIGN
             tile0 += ((R + 31) // 32) * ((C + 31) // 32)
             return o
+        def add_frag(w, kind, kchunk):     # vitpe_pack_weight_frags layout (block_tail2_fwd operands)
+            o = add(w, kind)
+            recs[-1] = recs[-1][:6] + (kchunk, 0)
+            return o
         spans = []
         for blk in self.model.blocks:
             for w in (blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight):
@@ -131,13 +140,19 @@ class TrainEngine:
                 spans.append((w, 0, add(w, 0)))
             if self.attn_fused:
                 spans.append((blk.attn.qkv.weight, 1, add(blk.attn.qkv.weight, 1)))
+            if self.tail2:
+                spans.append((blk.attn.proj.weight, 2, add_frag(blk.attn.proj.weight, 2, 192)))
+                spans.append((blk.mlp.fc1.weight, 3, add_frag(blk.mlp.fc1.weight, 3, 192)))
+                spans.append((blk.mlp.fc2.weight, 3, add_frag(blk.mlp.fc2.weight, 3, 32)))
         self._shadow_flat = torch.empty(off, dtype=self.T, device=self.dev)
         for w, kind, o in spans:
             R, C = w.shape
             if kind == 0:
                 self._st[id(w)] = self._shadow_flat[o:o + R * C].view(C, R)
-            else:
+            elif kind == 1:
                 self._pk[id(w)] = self._shadow_flat[o:o + R * C].view(R, C)
+            else:
+                self._fr[id(w)] = self._shadow_flat[o:o + R * C].view(R, C)
         import numpy as np
         rec = np.zeros(len(recs), dtype=np.dtype([("src", "<i8"), ("dst", "<i8"), ("R", "<i4"), ("C", "<i4"),
                                                    ("tile0", "<i4"), ("kind", "<i4"), ("HD", "<i4"), ("pad", "<i4")]))
@@ -165,6 +180,9 @@ class TrainEngine:
 
     def Pk(self, prm):  # packed qkv weights
         return self._pk[id(prm)]
+
+    def Fr(self, prm):  # fragment-major packed copy (block_tail2_fwd)
+        return self._fr[id(prm)]
 
     def refresh_shadows(self, cast_flat=True):
         if self.T == torch.bfloat16 and cast_flat:
@@ -319,6 +337,14 @@ class TrainEngine:
     def _block_tail_fwd(self, l, blk, a, nxt):
         M, D = self.M, self.D
         eps_next = self.model.blocks[min(l + 1, self.Lyr - 1)].norm1.eps
+        if self.tail2:   # wave-per-token-tile kernel on fragment-packed weights; keeps gelu'(u) in a["u"] instead of u
+            K.block_tail2_fwd(a["a"].view(M, D), self.x[l].view(M, D), self.Fr(blk.attn.proj.weight),
+                              blk.attn.proj.bias.data, blk.norm2.weight.data, blk.norm2.bias.data,
+                              self.Fr(blk.mlp.fc1.weight), blk.mlp.fc1.bias.data, self.Fr(blk.mlp.fc2.weight),
+                              blk.mlp.fc2.bias.data, x_mid=a["xmid"].view(M, D), mean2=a["m2"], rstd2=a["r2"],
+                              xn_out=(None if self.recompute_ln else a["xn2"].view(M, D)), gp=a["u"], h=a["h"],
+                              out=self.x[l + 1].view(M, D), stats=nxt, eps2=blk.norm2.eps, eps_next=eps_next)
+            return
         K.block_tail_fwd(a["a"].view(M, D), self.x[l].view(M, D), self.Sh(blk.attn.proj.weight),
                          blk.attn.proj.bias.data, blk.norm2.weight.data, blk.norm2.bias.data,
                          self.Sh(blk.mlp.fc1.weight), blk.mlp.fc1.bias.data, self.Sh(blk.mlp.fc2.weight),
@@ -331,7 +357,7 @@ class TrainEngine:
         K.block_tail_bwd(self.dx_out[l + 1].view(M, D), a["u"], self.St(blk.mlp.fc2.weight), self.St(blk.mlp.fc1.weight),
                          a["xmid"].view(M, D), a["m2"], a["r2"], blk.norm2.weight.data, G(blk.norm2.weight),
                          G(blk.norm2.bias), self.St(blk.attn.proj.weight), du=self.du_l[l], out=self.dx_mid[l].view(M, D),
-                         da=self.dtmp.view(M, D))
+                         da=self.dtmp.view(M, D), u_is_gprime=self.tail2)
 
     def _tail_bytes(self, fwd: bool) -> int:
         """Algorithmic HBM bytes of one block-tail launch (what the kernel must read and write once)."""
@@ -723,7 +749,9 @@ class TrainEngine:
                 blk, a = mdl.blocks[l], self.act[l]
                 return lambda: self._block_tail_bwd(l, blk, a)
             tail_flop = 2 * M * D * D + 2 * 2 * M * D * hid
-            probes.append(dict(name="block_tail_fwd", kernel="mlp_fwd_kernel (proj+residual+LN2+fc1+GELU+fc2+residual+stats)",
+            probes.append(dict(name="block_tail_fwd",
+                               kernel=("block_tail2_fwd_kernel" if self.tail2 else "mlp_fwd_kernel") +
+                               " (proj+residual+LN2+fc1+GELU+fc2+residual+stats)",
                                fns=[tail_f(l) for l in range(self.Lyr)], flop=tail_flop,
                                bytes=self._tail_bytes(fwd=True)))
             probes.append(dict(name="block_tail_bwd", kernel="mlp_fwd_kernel<BWD> (gelu'+dgrad fc2/fc1+LN2 bwd+residual+dgrad proj)",

@@ -164,6 +164,54 @@ def block_tail_fwd(attn_out, x_in, wp, bp, gamma, beta, w1, b1, w2, b2, x_mid=No
     return out, x_mid, mean2, rstd2, u, h
 
 
+def pack_weight_frags(w, dtype, kchunk, phi, out=None):
+    """Fragment-major packed copy of the fp32 weight w [R, C] (include/vitpe.h: vitpe_pack_weight_frags)."""
+    require_device(w, out)
+    _f32(w, "w")
+    R, C = w.shape
+    out = out if out is not None else torch.empty((R, C), dtype=dtype, device=w.device)
+    assert out.dtype == dtype and out.numel() == R * C
+    check(lib().vitpe_pack_weight_frags(dtype_code(dtype), ptr(w), ptr(out), R, C, int(kchunk), int(bool(phi)), stream_ptr()),
+          "vitpe_pack_weight_frags")
+    return out
+
+
+def block_tail2_supported(dtype, D, HID) -> bool:
+    return bool(lib().vitpe_block_tail2_supported(dtype_code(dtype), int(D), int(HID)))
+
+
+def block_tail2_fwd(attn_out, x_in, wp_pk, bp, gamma, beta, w1_pk, b1, w2_pk, b2, x_mid=None, mean2=None, rstd2=None,
+                    xn_out=None, gp=None, h=None, out=None, stats=None, eps2=1e-5, eps_next=1e-5, save=True):
+    """block_tail_fwd on packed weights (pack_weight_frags: wp kchunk 192 natural, w1 kchunk 192 phi, w2 kchunk 32
+    phi).  What it keeps of the hidden layer for backward is gp = gelu'(u) and h = gelu(u) (save=True), or nothing.
+    Returns (out, x_mid, mean2, rstd2, gp, h)."""
+    require_device(attn_out, x_in, wp_pk, bp, gamma, beta, w1_pk, b1, w2_pk, b2, x_mid, mean2, rstd2, xn_out, gp, h, out)
+    M, D = attn_out.shape
+    HID = b1.numel()
+    assert x_in.shape == (M, D) and wp_pk.numel() == D * D and w1_pk.numel() == HID * D and w2_pk.numel() == D * HID
+    assert attn_out.dtype == x_in.dtype == wp_pk.dtype == w1_pk.dtype == w2_pk.dtype
+    for t_, n_ in ((bp, "bp"), (gamma, "gamma"), (beta, "beta"), (b1, "b1"), (b2, "b2")):
+        _f32(t_, n_)
+    dt, dev = attn_out.dtype, attn_out.device
+    x_mid = x_mid if x_mid is not None else torch.empty((M, D), dtype=dt, device=dev)
+    mean2 = mean2 if mean2 is not None else torch.empty(M, dtype=torch.float32, device=dev)
+    rstd2 = rstd2 if rstd2 is not None else torch.empty(M, dtype=torch.float32, device=dev)
+    if save:
+        gp = gp if gp is not None else torch.empty((M, HID), dtype=dt, device=dev)
+        h = h if h is not None else torch.empty((M, HID), dtype=dt, device=dev)
+        assert gp.shape == h.shape == (M, HID) and gp.dtype == h.dtype == dt
+    else:
+        gp = h = None
+    out = out if out is not None else torch.empty((M, D), dtype=dt, device=dev)
+    mo, ro = stats if stats is not None else (None, None)
+    require_device(mo, ro)
+    check(lib().vitpe_block_tail2_fwd(dtype_code(dt), ptr(attn_out), ptr(x_in), ptr(wp_pk), ptr(bp), ptr(gamma), ptr(beta),
+                                      ptr(x_mid), ptr(mean2), ptr(rstd2), ptr(xn_out), ptr(w1_pk), ptr(b1), ptr(w2_pk),
+                                      ptr(b2), ptr(gp), ptr(h), ptr(out), ptr(mo), ptr(ro), float(eps2), float(eps_next),
+                                      M, D, HID, stream_ptr()), "vitpe_block_tail2_fwd")
+    return out, x_mid, mean2, rstd2, gp, h
+
+
 def mlp_bwd(dy, u, w2t, w1t, x, mean, rstd, gamma, dgamma, dbeta, du=None, out=None):
     """Backward of mlp_fwd w.r.t. x: -> (dx, du); dgamma/dbeta accumulated.  w2t = fc2.weight^T [HID,192],
     w1t = fc1.weight^T [192,HID]."""
@@ -180,8 +228,9 @@ def mlp_bwd(dy, u, w2t, w1t, x, mean, rstd, gamma, dgamma, dbeta, du=None, out=N
     return out, du
 
 
-def block_tail_bwd(dy, u, w2t, w1t, x, mean, rstd, gamma, dgamma, dbeta, wpt, du=None, out=None, da=None):
-    """mlp_bwd + da = dx @ proj.weight (wpt = proj.weight^T) in one kernel -> (dx, du, da)."""
+def block_tail_bwd(dy, u, w2t, w1t, x, mean, rstd, gamma, dgamma, dbeta, wpt, du=None, out=None, da=None, u_is_gprime=False):
+    """mlp_bwd + da = dx @ proj.weight (wpt = proj.weight^T) in one kernel -> (dx, du, da).  u_is_gprime: `u` holds
+    gelu'(u) as saved by block_tail2_fwd (vitpe_block_tail_bwd_gp) instead of the pre-activation."""
     require_device(dy, u, w2t, w1t, x, mean, rstd, gamma, dgamma, dbeta, wpt, du, out, da)
     M, D = dy.shape
     HID = u.shape[1]
@@ -191,9 +240,9 @@ def block_tail_bwd(dy, u, w2t, w1t, x, mean, rstd, gamma, dgamma, dbeta, wpt, du
     du = du if du is not None else torch.empty_like(u)
     out = out if out is not None else torch.empty_like(dy)
     da = da if da is not None else torch.empty_like(dy)
-    check(lib().vitpe_block_tail_bwd(dtype_code(dy.dtype), ptr(dy), ptr(u), ptr(w2t), ptr(w1t), ptr(x), ptr(mean), ptr(rstd),
-                                     ptr(gamma), ptr(du), ptr(out), ptr(dgamma), ptr(dbeta), ptr(wpt), ptr(da), M, D, HID,
-                                     stream_ptr()), "vitpe_block_tail_bwd")
+    fn = lib().vitpe_block_tail_bwd_gp if u_is_gprime else lib().vitpe_block_tail_bwd
+    check(fn(dtype_code(dy.dtype), ptr(dy), ptr(u), ptr(w2t), ptr(w1t), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(du),
+             ptr(out), ptr(dgamma), ptr(dbeta), ptr(wpt), ptr(da), M, D, HID, stream_ptr()), "vitpe_block_tail_bwd")
     return out, du, da
 
 
