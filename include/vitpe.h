@@ -183,6 +183,17 @@ int vitpe_block_tail2_fwd(int dtype, const void* attn_out, const void* x_in, con
                           void* xn_out, const void* W1_packed, const float* b1, const void* W2_packed,
                           const float* b2, void* gp_out, void* h_out, void* out, float* mean_out, float* rstd_out,
                           float eps2, float eps_next, int M, int D, int HID, vitpe_stream_t stream);
+/* vitpe_block_tail2_bwd: backward of vitpe_block_tail2_fwd w.r.t. its inputs, the same pipeline on the transposes:
+ *   du = (dy fc2.weight) * gp  [M,HID] (stored: fc1's weight gradient reads it),  dx_mid = dy + LayerNorm2'(du fc1.weight)
+ *   da = dx_mid attn.proj.weight  [M,192] (input of the attention backward);  dgamma / dbeta of norm2 accumulated (fp32
+ *   atomics, one per column and workgroup).  gp = gelu'(u) as saved by vitpe_block_tail2_fwd; x_mid / mean2 / rstd2 its
+ *   LayerNorm2 input rows and statistics.  Weights as vitpe_pack_weight_frags copies of the TRANSPOSES:
+ *   W2t_packed = pack(fc2.weight^T [HID,192], kchunk 192, phi 0), W1t_packed = pack(fc1.weight^T [192,HID], kchunk 32, phi 1),
+ *   WpT_packed = pack(attn.proj.weight^T [192,192], kchunk 192, phi 1).  Support as vitpe_block_tail2_fwd.                 */
+int vitpe_block_tail2_bwd(int dtype, const void* dy, const void* gp, const void* W2t_packed, const void* W1t_packed,
+                          const void* x_mid, const float* mean2, const float* rstd2, const float* gamma, void* du,
+                          void* dx_mid, float* dgamma, float* dbeta, const void* WpT_packed, void* da, int M, int D,
+                          int HID, vitpe_stream_t stream);
 /* vitpe_mlp_bwd: backward of that branch w.r.t. its input, same pipeline on the transposed weight shadows:
  *   du = (dy fc2.weight) * gelu'(u)   [M,HID], stored (the fc1 weight gradient reads it)
  *   dx = dy + LayerNorm'(du fc1.weight) ; dgamma / dbeta accumulated (fp32 atomics)

@@ -404,3 +404,36 @@ def test_bf16_captured_step_with_layernorm_outputs_recomputed(monkeypatch):
     bad = compare_all("rope-mixed/recompute-ln", model, grads, ref_grads, report)
     _dump(report, "bench_path_parity.jsonl")
     assert rel_err(eng.logits.cpu(), ref_logits) <= 5e-2 and not bad, bad
+
+
+def test_engine_fragment_packed_shadows_match_the_pack_entry_point_and_first_generation_tail(monkeypatch):
+    """The second-generation block tail reads attn.proj / fc1 / fc2 from fragment-packed shadows that the batched
+    refresh kernel rewrites after every optimizer step: they must equal vitpe_pack_weight_frags of the fp32 masters
+    (before and after a step), and VITPE_TAIL2=0 (first-generation kernels, u saved instead of gelu'(u)) must give the
+    same gradients within bf16 noise."""
+    from vitpe import kernels as K
+    from vitpe.engine import TrainEngine
+    B = 16
+    g = torch.Generator().manual_seed(11)
+    images, labels = torch.randn(B, 3, 32, 32, generator=g).cuda(), torch.randint(0, 10, (B,), generator=g).cuda()
+
+    def packed_ok(eng):
+        for blk in eng.model.blocks:
+            for w, kch, phi in ((blk.attn.proj.weight, 192, 0), (blk.mlp.fc1.weight, 192, 1), (blk.mlp.fc2.weight, 32, 1)):
+                ref = K.pack_weight_frags(w.data.contiguous(), torch.bfloat16, kch, phi)
+                assert torch.equal(eng.Fr(w).reshape(-1).cpu(), ref.reshape(-1).cpu())
+
+    _, model = build("rope-axial", {}, {}, seeded=True)
+    eng = TrainEngine(model, B, compute_dtype=torch.bfloat16, use_graph=True)
+    assert eng.tail2
+    packed_ok(eng)
+    g2 = graph_step_gradients(eng, images, labels)
+    packed_ok(eng)                                   # after the captured step's refresh
+    monkeypatch.setenv("VITPE_TAIL2", "0")
+    _, model1 = build("rope-axial", {}, {}, seeded=True)
+    eng1 = TrainEngine(model1, B, compute_dtype=torch.bfloat16, use_graph=True)
+    assert not eng1.tail2
+    g1 = graph_step_gradients(eng1, images, labels)
+    for n in g1:
+        if float(g1[n].abs().max()) > 0:
+            assert rel_err(g2[n].numpy(), g1[n].numpy()) < 3e-2, n

@@ -420,6 +420,42 @@ def test_block_tail_backward_from_saved_gelu_derivative(K):
     assert rel_err(dg2.cpu(), dg1.cpu()) < 5e-3 and rel_err(db2.cpu(), db1.cpu()) < 5e-3
 
 
+@pytest.mark.parametrize("M,HID", [(650, 768), (130 * 2 + 5, 768), (33280, 768), (13, 128), (16 * 2048 + 16 * 40 + 3, 768)])
+def test_block_tail2_backward_equals_first_generation_on_saved_derivative(K, M, HID):
+    """The wave-per-token-tile backward (packed transposed weights) against the first-generation backward fed the same
+    gelu'(u), and its du / dx_mid / da / dgamma / dbeta against fp32 math on the rounded operands."""
+    D, bf = 192, torch.bfloat16
+    x, g = rnd(M, D, seed=41), 1 + 0.1 * rnd(D, seed=42)
+    dy, gp = rnd(M, D, seed=43), 0.5 + 0.6 * rnd(M, HID, seed=44)
+    w2, w1, wp = rnd(D, HID, seed=45, scale=0.05), rnd(HID, D, seed=46, scale=0.08), rnd(D, D, seed=47, scale=0.07)
+    xd = dev(x, bf)
+    _, mean, rstd = K.layernorm_fwd(xd, dev(g), torch.zeros(D, device="cuda"))
+    w2t_pk = K.pack_weight_frags(dev(w2.t().contiguous()), bf, 192, 0)
+    w1t_pk = K.pack_weight_frags(dev(w1.t().contiguous()), bf, 32, 1)
+    wpt_pk = K.pack_weight_frags(dev(wp.t().contiguous()), bf, 192, 1)
+    dg2, db2 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    dx2, du2, da2 = K.block_tail2_bwd(dev(dy, bf), dev(gp, bf), w2t_pk, w1t_pk, xd, mean, rstd, dev(g), dg2, db2, wpt_pk)
+    if K.mlp_fwd_supported(bf, D, HID):
+        dg1, db1 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+        dx1, du1, da1 = K.block_tail_bwd(dev(dy, bf), dev(gp, bf), dev(w2.t().contiguous(), bf), dev(w1.t().contiguous(), bf), xd,
+                                         mean, rstd, dev(g), dg1, db1, dev(wp.t().contiguous(), bf), u_is_gprime=True)
+        assert rel_err(du2.float().cpu(), du1.float().cpu()) < 8e-3
+        assert rel_err(dx2.float().cpu(), dx1.float().cpu()) < 8e-3 and rel_err(da2.float().cpu(), da1.float().cpu()) < 8e-3
+        assert rel_err(dg2.cpu(), dg1.cpu()) < 5e-3 and rel_err(db2.cpu(), db1.cpu()) < 5e-3
+    # fp32 math on the rounded operands, stage by stage from the kernel's own (rounded) intermediates
+    dyq, gpq, xq = q(dy, "bf16"), q(gp, "bf16"), q(x, "bf16")
+    du_ref = (dyq @ q(w2, "bf16")) * gpq
+    assert rel_err(du2.float().cpu(), du_ref) < 6e-3
+    dxn = du2.float().cpu() @ q(w1, "bf16")                      # [M, D]
+    mu, rs = mean.cpu()[:, None], rstd.cpu()[:, None]
+    xhat = (xq - mu) * rs
+    gy = dxn * g
+    dx_ref = dyq + rs * (gy - gy.mean(1, keepdim=True) - xhat * (gy * xhat).mean(1, keepdim=True))
+    assert rel_err(dx2.float().cpu(), dx_ref) < 6e-3
+    assert rel_err(dg2.cpu(), (dxn * xhat).sum(0)) < 2e-3 and rel_err(db2.cpu(), dxn.sum(0)) < 2e-3
+    assert rel_err(da2.float().cpu(), dx2.float().cpu() @ q(wp, "bf16")) < 6e-3
+
+
 def test_fused_mlp_unsupported_is_an_error(K):
     from vitpe._lib import VitpeError
     z = lambda *s: torch.zeros(*s, device="cuda")  # noqa: E731

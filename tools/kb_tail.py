@@ -51,11 +51,30 @@ def main():
                           xn_out=xn[i] if store_xn else None, gp=u[i] if save else None, h=h[i] if save else None, out=y[i],
                           stats=(mo, ro), save=save)
 
+    # backward
+    dy = [r(M, D).to(T) for _ in range(ROT)]
+    du, dxm, da = [e(M, HID) for _ in range(ROT)], [e(M, D) for _ in range(ROT)], [e(M, D) for _ in range(ROT)]
+    w2t, w1t, wpt = w2.t().contiguous(), w1.t().contiguous(), wp.t().contiguous()
+    w2tb, w1tb, wptb = w2t.to(T), w1t.to(T), wpt.to(T)
+    w2tk, w1tk, wptk = K.pack_weight_frags(w2t, T, 192, 0), K.pack_weight_frags(w1t, T, 32, 1), K.pack_weight_frags(wpt, T, 192, 1)
+    dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    K.layernorm_fwd(xm[0], gam, bet, mean=m2, rstd=r2, stats_only=True)
+
+    def bwd1(i):
+        K.block_tail_bwd(dy[i], u[i], w2tb, w1tb, xm[i], m2, r2, gam, dg, db, wptb, du=du[i], out=dxm[i], da=da[i], u_is_gprime=True)
+
+    def bwd2(i):
+        K.block_tail2_bwd(dy[i], u[i], w2tk, w1tk, xm[i], m2, r2, gam, dg, db, wptk, du=du[i], out=dxm[i], da=da[i])
+
     for name, fn in (("block_tail_fwd  (gen 1)", gen1), ("block_tail2_fwd (gen 2)", gen2),
                      ("block_tail2_fwd no xn", lambda i: gen2(i, store_xn=False)),
                      ("block_tail2_fwd inference", lambda i: gen2(i, save=False, store_xn=False))):
         us = timeit(fn, rot=ROT)
         print(f"B={B} {name:30s} {us:8.2f} us = {flop / us / 1e6:7.1f} TF   {byts / us / 1e3:7.1f} GB/s (full-store bytes)", flush=True)
+    bb = (4 * M * D + 2 * M * HID) * 2
+    for name, fn in (("block_tail_bwd  (gen 1, gp)", bwd1), ("block_tail2_bwd (gen 2)", bwd2)):
+        us = timeit(fn, rot=ROT)
+        print(f"B={B} {name:30s} {us:8.2f} us = {flop / us / 1e6:7.1f} TF   {bb / us / 1e3:7.1f} GB/s", flush=True)
 
 
 if __name__ == "__main__":

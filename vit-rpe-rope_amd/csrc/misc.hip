@@ -660,7 +660,7 @@ __global__ void transpose_cast_kernel(const float* __restrict__ src, T* __restri
 // All weight shadows of the model in ONE launch (after the optimizer step): a descriptor per matrix,
 // each workgroup handles one 32x32 tile.  kind 0: dst[c][r] = src[r][c] (transposed shadow for the
 // data-gradient GEMMs); kind 1: fragment-major packing of attn.qkv.weight (see pack_qkv_kernel); kind 2 / 3: the
-// fragment-major packing of tail2.hip (natural / acc_to_frag k order, HD field = k chunk).
+// fragment-major packing of tail2.hip (natural / acc_to_frag k order, HD field = k chunk); kind 4 / 5: the same of W^T.
 struct ShadowDesc { long long src_off, dst_off; int R, C, tile0, kind, HD, pad; };
 
 template <typename T>
@@ -688,19 +688,27 @@ __global__ __launch_bounds__(256) void refresh_shadows_kernel(const float* __res
       if (c < ds.C && r < ds.R) dst[(size_t)c * ds.R + r] = from_f32<T>(tile[tx][i]);
     }
   } else if (ds.kind >= 2) {
-    // vitpe_pack_weight_frags layout (tail2.hip): HD field = k chunk; kind 2 natural k order, kind 3 acc_to_frag order
-    const int kch = ds.HD, KSC = kch / 32, NTr = ds.R / 16;
-    for (int i = ty; i < 32; i += 8) {
-      const int r = r0 + i, c = c0 + tx;
-      if (r < ds.R && c < ds.C) {
-        const int nt = r / 16, cc = r % 16, kc = c / kch, ks = (c % kch) / 32, k = c % 32;
-        int g, e;
-        if (ds.kind == 2) { g = k / 8; e = k % 8; }
-        else if (k < 16) { g = k / 4; e = k % 4; }
-        else { g = (k - 16) / 4; e = 4 + (k - 16) % 4; }
-        const size_t blk = ((size_t)kc * NTr + nt) * KSC + ks;
-        dst[(blk * 64 + 16 * g + cc) * 8 + e] = from_f32<T>(tile[i][tx]);
+    // vitpe_pack_weight_frags layout (tail2.hip): HD field = k chunk; kinds 2 / 3 pack W itself in natural / acc_to_frag
+    // k order, kinds 4 / 5 pack W^T (the backward kernel's operands) the same two ways.
+    // A 32x32 tile is exactly two 1-KB fragments (output tiles p0/16, p0/16 + 1 of one k step): every thread writes 4
+    // consecutive destination elements (both dimensions are multiples of 32 for these matrices).
+    const bool tr = ds.kind >= 4, phi = (ds.kind & 1) != 0;
+    const int PR = tr ? ds.C : ds.R;                       // rows of the packed matrix
+    const int p0 = tr ? c0 : r0, k0 = tr ? r0 : c0;        // its row / column origin of this tile
+    const int kch = ds.HD, KSC = kch / 32, NTr = PR / 16;
+    const int kc = k0 / kch, ks = (k0 % kch) / 32;
+    const int d = threadIdx.x * 4, frag = d >> 9, within = d & 511, l = within >> 3, e0 = within & 7;
+    const int nt = p0 / 16 + frag, cc = l & 15, g = l >> 4;
+    if (16 * nt < PR) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = e0 + j;
+        const int k = phi ? (e < 4 ? 4 * g + e : 16 + 4 * g + e - 4) : 8 * g + e;
+        v[j] = tr ? tile[k][16 * frag + cc] : tile[16 * frag + cc][k];
       }
+      const size_t blk = ((size_t)kc * NTr + nt) * KSC + ks;
+      st4(dst + blk * 512 + within, v[0], v[1], v[2], v[3]);
     }
   } else {
     // W[3D, D]: row = mat*D + h*HD + 16nt + cc ; col = 32ks + 8g + e  ->  block (h,mat,nt,ks), lane 16g+cc, e

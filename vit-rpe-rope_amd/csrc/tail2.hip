@@ -34,6 +34,9 @@
 #ifndef T2_NT_HID
 #define T2_NT_HID true
 #endif
+#ifndef T2_RB
+#define T2_RB 6
+#endif
 #ifndef T2_NV
 #define T2_NV 8
 #endif
@@ -161,18 +164,18 @@ VITPE_DEV void t2_gelu(float x, float& h, float& g) {
   g = x >= 0.f ? 1.0f + r : -r;
 }
 
-// One step of the three-stage pipeline over 32-wide hidden sub-chunks t:
+// One step of the three-stage pipeline over 32-wide hidden sub-chunks t (forward; the backward kernel runs the same
+// pipeline on the transposed weights with its own G stage):
 //   F1: fc1 product of sub-chunk t + 1  (12 MFMAs: 2 output tiles x 6 k steps, B = the LayerNorm2 fragments)  -> a1n
-//   G : GELU epilogue of sub-chunk t    (a1c = u with bias -> h fragment hnew; SAVE: h and g' rows stored)
+//   G : elementwise epilogue of sub-chunk t, a callable (forward: GELU; backward: times gelu'(u))
 //   F2: fc2 product of sub-chunk t - 1  (12 MFMAs: 12 output tiles x 1 k step, B = hprev)                      -> acc2
 // The three are independent, so they go into ONE scheduling region: the two products' fragments alternate through one
 // ring of R registers and every MFMA is followed by NV VALU instructions of the epilogue.
 // w1f / w2f: lane-offset LDS pointers to the sub-chunk's fragments (fc1: (tile * 6 + k step) * 512, fc2: tile * 512).
-template <bool F1, bool G, bool F2, bool SAVE, int EXP = 0>
-VITPE_DEV void t2_substep(const bf16* w1f, const bf16* w2f, const Frag<bf16> (&bf)[T2_KS], f32x4 (&a1n)[2],
-                          const f32x4 (&a1c)[2], const Frag<bf16>& hprev, Frag<bf16>& hnew, f32x4 (&acc2)[T2_NT],
-                          bf16* gpr, bf16* hr, int g) {
-  constexpr int R = 8, TOT = (F1 ? 12 : 0) + (F2 ? 12 : 0), NV = (F1 && F2) ? T2_NV : 2 * T2_NV;
+template <bool F1, bool F2, int NV, int EXP, int R = 8, class GFn>
+VITPE_DEV void t2_step(const bf16* w1f, const bf16* w2f, const Frag<bf16> (&bf)[T2_KS], f32x4 (&a1n)[2],
+                       const Frag<bf16>& hprev, f32x4 (&acc2)[T2_NT], GFn gfn) {
+  constexpr int TOT = (F1 ? 12 : 0) + (F2 ? 12 : 0);
   __builtin_amdgcn_sched_barrier(0);
   if (TOT > 0) {
     // unified fragment list: both products -> even q = fc2 fragment q / 2, odd q = fc1 fragment q / 2
@@ -193,7 +196,27 @@ VITPE_DEV void t2_substep(const bf16* w1f, const bf16* w2f, const Frag<bf16> (&b
       else mma(w[q % R], bf[j / 2], a1n[j % 2]);
     }
   }
-  if (G) {
+  gfn();      // the G stage (nothing when NV == 0)
+  if (TOT > 0) {
+    __builtin_amdgcn_sched_group_barrier(0x100, R - 1, 0);
+#pragma unroll
+    for (int q = 0; q < TOT; ++q) {
+      if (q + R - 1 < TOT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // one MFMA
+      if (NV > 0) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);           // NV VALU instructions of the G stage
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// forward: G = GELU of sub-chunk t (a1c = u with bias -> h fragment hnew; SAVE: h and g' rows stored)
+template <bool F1, bool G, bool F2, bool SAVE, int EXP = 0>
+VITPE_DEV void t2_substep(const bf16* w1f, const bf16* w2f, const Frag<bf16> (&bf)[T2_KS], f32x4 (&a1n)[2],
+                          const f32x4 (&a1c)[2], const Frag<bf16>& hprev, Frag<bf16>& hnew, f32x4 (&acc2)[T2_NT],
+                          bf16* gpr, bf16* hr, int g) {
+  constexpr int NV = !G ? 0 : (F1 && F2) ? T2_NV : 2 * T2_NV;
+  t2_step<F1, F2, NV, EXP>(w1f, w2f, bf, a1n, hprev, acc2, [&]() {
+    if (!G) return;
     // scalar fp32 on purpose: packed f32 VALU (v_pk_mul/fma_f32) issues several times slower than two scalar
     // instructions beside MFMAs on gfx950 (MI355X_MICROARCH.md, issue-cost table), and this epilogue IS the bound
     f32x4 gp[2], hh[2];
@@ -214,17 +237,7 @@ VITPE_DEV void t2_substep(const bf16* w1f, const bf16* w2f, const Frag<bf16> (&b
       t2_store_pair<T2_NT_HID>(hr, 0, g, hh[0], hh[1]);
     }
     hnew = acc_to_frag<bf16>(hh[0], hh[1]);
-  }
-  if (TOT > 0) {
-    __builtin_amdgcn_sched_group_barrier(0x100, R - 1, 0);
-#pragma unroll
-    for (int q = 0; q < TOT; ++q) {
-      if (q + R - 1 < TOT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // one MFMA
-      if (G) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);                // NV VALU instructions of the epilogue
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
+  });
 }
 
 template <bool SAVE, bool CENSUS, int EXP = 0>
@@ -473,6 +486,292 @@ __global__ __launch_bounds__(T2_THREADS) void block_tail2_fwd_kernel(Tail2Args a
   stamp(9);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of the block tail w.r.t. its inputs (the weight gradients are the grouped wgrad kernel's): the same pipeline on
+// the transposed weights.  Per 16-token tile, everything transposed ([feature][token] accumulators):
+//   dh  = dy W2            F1 stage: A = fc2.weight^T rows of the hidden sub-chunk (natural k order), B = dy fragments
+//   du  = dh * gelu'(u)    G stage: gp rows loaded 2 sub-chunks ahead, du rows stored (fc1's weight gradient reads them)
+//   dxn = du W1            F2 stage: A = fc1.weight^T (k = hidden sub-chunk, acc_to_frag order), B = du fragments
+//   dx_mid = dy + LayerNorm2'(dxn)   (row statistics saved by the forward; dgamma / dbeta: DPP row sums over the 16 tokens,
+//                                     LDS atomics per workgroup, one global atomic per column and workgroup)
+//   da  = dx_mid Wp        A = attn.proj.weight^T (acc_to_frag order), loaded into the slab buffers once they are free
+struct Tail2BwdArgs {
+  const void* dy;       // [M,192] gradient of the block output
+  const void* gp;       // [M,HID] gelu'(u) (vitpe_block_tail2_fwd)
+  const void* xmid;     // [M,192] LayerNorm2's input rows
+  const float* mean2;   // [M]
+  const float* rstd2;
+  const float* gamma;   // norm2.weight [192]
+  const void* w2t;      // pack(fc2.weight^T [HID,192], kchunk 192, natural)
+  const void* w1t;      // pack(fc1.weight^T [192,HID], kchunk 32, phi)
+  const void* wpt;      // pack(attn.proj.weight^T [192,192], kchunk 192, phi)
+  void* du;             // [M,HID] out
+  void* dxmid;          // [M,192] out
+  void* da;             // [M,192] out
+  float* dgamma;        // [192] accumulated
+  float* dbeta;
+  int M, HID;
+};
+
+// inverse of t2_store_pair: lane (c, g) loads the 8 contiguous features it would have stored and gets back the two tiles'
+// [feature 4g + r][token c] values (v_permlane16_swap is an involution)
+VITPE_DEV void t2_unpack_pair(const Chunk16& v, f32x4& o0, f32x4& o1) {
+#pragma unroll
+  for (int w2 = 0; w2 < 2; ++w2) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v[w2], v[2 + w2], false, false);
+    o0[2 * w2] = __uint_as_float(r[0] << 16);
+    o0[2 * w2 + 1] = __uint_as_float(r[0] & 0xffff0000u);
+    o1[2 * w2] = __uint_as_float(r[1] << 16);
+    o1[2 * w2 + 1] = __uint_as_float(r[1] & 0xffff0000u);
+  }
+}
+
+// Column sums of 8 values over the 16 lanes of a DPP row (the 16 tokens of a tile) as a halving butterfly: each step a
+// lane keeps half of its values and adds its partner's copy of that half (partners: lane ^ 8, 7 - lane within the 8, ^ 2,
+// ^ 1), 15 DPP moves instead of 32.  Lane c ends with the total of value 4 b3 + 2 b2 + b1 (bits of c; b0 ignored).
+template <int CTRL> VITPE_DEV float t2_dppc(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+VITPE_DEV float t2_colsum8(const float (&t)[8], int c) {
+  const bool b3 = (c & 8) != 0, b2 = (c & 4) != 0, b1 = (c & 2) != 0;
+  float u[4], w[2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) u[k] = (b3 ? t[4 + k] : t[k]) + t2_dppc<0x128>(b3 ? t[k] : t[4 + k]);        // row_ror:8
+#pragma unroll
+  for (int k = 0; k < 2; ++k) w[k] = (b2 ? u[2 + k] : u[k]) + t2_dppc<0x141>(b2 ? u[k] : u[2 + k]);        // row_half_mirror
+  const float x = (b1 ? w[1] : w[0]) + t2_dppc<0x4E>(b1 ? w[0] : w[1]);                                    // quad_perm [2,3,0,1]
+  return x + t2_dppc<0xB1>(x);                                                                               // quad_perm [1,0,3,2]
+}
+
+__global__ __launch_bounds__(T2_THREADS) void block_tail2_bwd_kernel(Tail2BwdArgs a) {
+  using T = bf16;
+  constexpr int D = T2_D, NT = T2_NT, KS = T2_KS;
+  __shared__ __attribute__((aligned(16))) T sW[3 * T2_SLABF * 512];
+  __shared__ __attribute__((aligned(16))) float sGam[T2_D];
+  __shared__ float sAcc[2 * T2_D];                    // dgamma | dbeta of this workgroup
+  __shared__ int sReady[T2_NFLAG], sDone[T2_NFLAG], sFin;
+
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int HID = a.HID, nchunk = HID / T2_CH, nsub = 2 * nchunk;
+  const int ntiles = (a.M + 15) / 16, base = ntiles / (int)gridDim.x, rem = ntiles % (int)gridDim.x;
+  const int tile0 = (int)blockIdx.x * base + min((int)blockIdx.x, rem), ntile_wg = base + ((int)blockIdx.x < rem ? 1 : 0);
+  const bool active = wave < ntile_wg;
+  const int row = 16 * (tile0 + wave) + c;
+  const int rowc = min(row, a.M - 1);                 // rows past M: computed as copies of row M - 1, masked out of the sums
+  const float valid = row < a.M ? 1.0f : 0.0f;
+
+  if (threadIdx.x < T2_NFLAG) { sReady[threadIdx.x] = 0; sDone[threadIdx.x] = 0; }
+  if (threadIdx.x == 0) sFin = 0;
+  for (int i = threadIdx.x; i < 2 * D; i += T2_THREADS) sAcc[i] = 0.f;
+  for (int i = threadIdx.x; i < D; i += T2_THREADS) sGam[i] = a.gamma[i];
+
+  auto dma1 = [&](const T* src_frag, int dst_frag) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_frag + lane * 8),
+                                     (__attribute__((address_space(3))) void*)(sW + dst_frag * 512), 16, 0, 0);
+  };
+  // ---- waves 9 and 10: the loaders (see the forward kernel): wave 9 the F1 halves of slabs 0 .. nchunk - 1 (fc2.weight^T),
+  // wave 10 the F2 halves of slabs 1 .. nchunk (fc1.weight^T); a half buffer is reused only by the same loader's slab s + 3.
+  // When every slab has been consumed both load their half of attn.proj.weight^T into fragments [0, 72).
+  if (wave >= T2_WAVES) {
+    const bool is1 = wave == T2_WAVES;
+    const int first = is1 ? 0 : 1, last = is1 ? nchunk - 1 : nchunk;
+    const T* const src = is1 ? reinterpret_cast<const T*>(a.w2t) : reinterpret_cast<const T*>(a.w1t) - (size_t)T2_HALF * 512;
+    const int half = is1 ? 0 : T2_HALF;
+    auto dma_half = [&](int sl) {
+      const int b0 = ((sl + 2) % 3) * T2_SLABF + half;
+#pragma unroll
+      for (int f = 0; f < T2_HALF; ++f) dma1(src + ((size_t)sl * T2_HALF + f) * 512, b0 + f);
+    };
+    auto wait_done = [&](int k) {
+      while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sDone[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < ntile_wg)
+        __builtin_amdgcn_s_sleep(2);
+      asm volatile("" ::: "memory");
+    };
+    auto raise = [&](int sl) {
+      asm volatile("" ::: "memory");
+      if (lane == 0) atomicAdd(&sReady[sl], 1);
+    };
+    __builtin_amdgcn_s_waitcnt(0x0070);         // lgkmcnt(0): the LDS initialisation above
+    asm volatile("s_barrier" ::: "memory");     // the one barrier
+    dma_half(first);
+    if (first + 1 <= last) dma_half(first + 1);
+    for (int sl = first; sl <= last; ++sl) {
+      if (sl + 1 <= last) __builtin_amdgcn_s_waitcnt(0x4F78);   // vmcnt(24): only slab sl + 1's pieces may be in flight
+      else __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+      raise(sl);
+      if (sl + 2 <= last) {
+        if (sl - 1 >= first) wait_done(sl);                     // sDone[sl] counts slab sl - 1, whose half buffer slab sl + 2 takes
+        dma_half(sl + 2);
+      }
+    }
+    wait_done(nchunk + 1);                                      // every slab consumed by every active wave
+#pragma unroll
+    for (int f = 0; f < NT * KS / 2; ++f) {
+      const int ff = (is1 ? 0 : NT * KS / 2) + f;
+      dma1(reinterpret_cast<const T*>(a.wpt) + (size_t)ff * 512, ff);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    raise(nchunk + 1);
+    return;
+  }
+  auto wait_ready = [&](int sl) {
+    const int need = sl > nchunk ? 2 : (sl < nchunk ? 1 : 0) + (sl >= 1 ? 1 : 0);
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sReady[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need)
+      __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+  };
+  auto signal_done = [&](int k) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) atomicAdd(&sDone[k], 1);
+  };
+
+  // ---- compute waves: dy rows as B fragments (natural k order) --------------------------------------------------------------
+  Frag<T> bf[KS];
+  if (active) {
+    const T* dr = reinterpret_cast<const T*>(a.dy) + (size_t)rowc * D + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bf[ks] = ld_frag(dr + 32 * ks);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0070);           // vmcnt(0) lgkmcnt(0)
+  asm volatile("s_barrier" ::: "memory");       // the one barrier
+  if (!active) return;
+
+  const T* const gpr = reinterpret_cast<const T*>(a.gp) + (size_t)rowc * HID + 16 * (g & 1) + 8 * (g >> 1);
+  T* const dur = reinterpret_cast<T*>(a.du) + (size_t)rowc * HID;
+  Chunk16 gq[2];                                 // gelu'(u) rows of sub-chunks t, t + 1 in flight (slot t & 1)
+#pragma unroll
+  for (int t = 0; t < 2; ++t) gq[t] = *reinterpret_cast<const Chunk16*>(gpr + 32 * t);
+  f32x4 acc2[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc2[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 aX[2], aY[2];
+  Frag<T> hP, hQ;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  // G stage of sub-chunk t: du = dh * gelu'(u) -> stored, -> B fragment of the F2 product; refills its prefetch slot
+  auto gstage = [&](const f32x4 (&a1c)[2], Chunk16& slot, int t, Frag<T>& hnew) {
+    f32x4 g0, g1, d0, d1;
+    t2_unpack_pair(slot, g0, g1);
+    if (t + 2 < nsub) slot = *reinterpret_cast<const Chunk16*>(gpr + 32 * (t + 2));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { d0[r] = a1c[0][r] * g0[r]; d1[r] = a1c[1][r] * g1[r]; }
+    t2_store_pair<true>(dur + 32 * t, 0, g, d0, d1);
+    hnew = acc_to_frag<T>(d0, d1);
+  };
+  constexpr int NVB = 3, RB = T2_RB;    // VALU instructions of the G stage per MFMA (it is short: the step is matrix-pipe bound)
+
+  wait_ready(0);
+  {
+    const T* wb = sW + 2 * T2_SLABF * 512 + lane * 8;
+    aX[0] = z4; aX[1] = z4;
+    t2_step<true, false, 0, 0, RB>(wb, wb, bf, aX, hQ, acc2, [&]() {});                                             // F1_0
+    aY[0] = z4; aY[1] = z4;
+    t2_step<true, false, 2 * NVB, 0, RB>(wb + 2 * KS * 512, wb, bf, aY, hQ, acc2, [&]() { gstage(aX, gq[0], 0, hP); });   // F1_1 G_0
+    signal_done(1);
+  }
+  for (int p = 1; p < nchunk; ++p) {
+    wait_ready(p);
+    const T* wb = sW + ((p + 2) % 3) * T2_SLABF * 512 + lane * 8;
+    const T* w2b = wb + T2_HALF * 512;
+    aX[0] = z4; aX[1] = z4;
+    t2_step<true, true, NVB, 0, RB>(wb, w2b, bf, aX, hP, acc2, [&]() { gstage(aY, gq[1], 2 * p - 1, hQ); });
+    aY[0] = z4; aY[1] = z4;
+    t2_step<true, true, NVB, 0, RB>(wb + 2 * KS * 512, w2b + NT * 512, bf, aY, hQ, acc2, [&]() { gstage(aX, gq[0], 2 * p, hP); });
+    signal_done(p + 1);
+  }
+  wait_ready(nchunk);
+  {
+    const T* w2b = sW + ((nchunk + 2) % 3) * T2_SLABF * 512 + T2_HALF * 512 + lane * 8;
+    const int tl = nsub - 1;
+    t2_step<false, true, 2 * NVB, 0, RB>(w2b, w2b, bf, aX, hP, acc2, [&]() { gstage(aY, gq[1], tl, hQ); });
+    t2_step<false, true, 0, 0, RB>(w2b, w2b + NT * 512, bf, aX, hQ, acc2, [&]() {});                                  // F2_last
+    signal_done(nchunk + 1);
+  }
+  // LayerNorm input rows (only now are there registers for them)
+  bf16x4 xmv[NT];
+  {
+    const T* xr = reinterpret_cast<const T*>(a.xmid) + (size_t)rowc * D + 4 * g;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) xmv[nt] = *reinterpret_cast<const bf16x4*>(xr + 16 * nt);
+  }
+  const float mean = a.mean2[rowc], rstd = a.rstd2[rowc];
+
+  // ---- LayerNorm2 backward + residual: dx_mid = dy + rstd (gy - mean_f(gy) - xhat mean_f(gy xhat)), gy = dxn gamma ----------
+  const float invD = 1.0f / (float)D;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x4 gam = *reinterpret_cast<const f32x4*>(sGam + 16 * nt + 4 * g);
+    float tot[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float xhat = ((float)xmv[nt][r] - mean) * rstd;
+      const float dxn = acc2[nt][r];
+      tot[r] = dxn * xhat * valid;       // dgamma / dbeta contributions (rows past M masked)
+      tot[4 + r] = dxn * valid;
+      const float gy = dxn * gam[r];
+      s1 += gy;
+      s2 = fmaf(gy, xhat, s2);
+    }
+    // column sums over the tile's 16 tokens: even lane c of every row ends with total (c >> 1): one LDS atomic per tile
+    const float sel = t2_colsum8(tot, c);
+    if (!(c & 1)) atomicAdd(&sAcc[(c < 8 ? 0 : D - 4) + 16 * nt + 4 * g + (c >> 1)], sel);
+  }
+  const float m1 = t2_xg_sum(s1) * invD, m2 = t2_xg_sum(s2) * invD;
+  bf16x4 dyv[NT];                                  // the residual rows
+  {
+    const T* dr = reinterpret_cast<const T*>(a.dy) + (size_t)rowc * D + 4 * g;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) dyv[nt] = *reinterpret_cast<const bf16x4*>(dr + 16 * nt);
+  }
+  // second pass: gy and xhat are recomputed from the packed rows (keeping 48 fp32 xhat values alive across the row sums
+  // is what spilled); the empty asm stops the compiler from re-using the first pass's conversions
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    __builtin_amdgcn_sched_barrier(0);
+    uint2 xw = __builtin_bit_cast(uint2, xmv[nt]);
+    asm volatile("" : "+v"(xw.x), "+v"(xw.y));
+    const bf16x4 xb = __builtin_bit_cast(bf16x4, xw);
+    const f32x4 gam = *reinterpret_cast<const f32x4*>(sGam + 16 * nt + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float xhat = ((float)xb[r] - mean) * rstd;
+      const float gy = acc2[nt][r] * gam[r];
+      acc2[nt][r] = to_f32(from_f32<T>(fmaf(rstd, gy - m1 - xhat * m2, (float)dyv[nt][r])));   // as stored
+    }
+  }
+  {
+    T* const dxr = reinterpret_cast<T*>(a.dxmid) + (size_t)rowc * D;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt += 2) t2_store_pair<false>(dxr, nt, g, acc2[nt], acc2[nt + 1]);
+  }
+  // ---- da = dx_mid Wp ----------------------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) bf[ks] = acc_to_frag<T>(acc2[2 * ks], acc2[2 * ks + 1]);
+  f32x4 accA[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) accA[nt] = z4;
+  wait_ready(nchunk + 1);
+  t2_gemm<NT, KS, 12>(sW + lane * 8, bf, accA);
+  {
+    T* const dar = reinterpret_cast<T*>(a.da) + (size_t)rowc * D;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt += 2) t2_store_pair<false>(dar, nt, g, accA[nt], accA[nt + 1]);
+  }
+  // ---- the last wave of the workgroup hands the column sums to the global accumulators ----------------------------------------
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  int fin = 0;
+  if (lane == 0) fin = atomicAdd(&sFin, 1);
+  fin = __builtin_amdgcn_readfirstlane(fin);
+  if (fin == ntile_wg - 1) {
+    for (int i = lane; i < D; i += 64) {
+      atomicAdd(a.dgamma + i, __hip_atomic_load(&sAcc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      atomicAdd(a.dbeta + i, __hip_atomic_load(&sAcc[D + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    }
+  }
+}
+
 // Fragment-major packed copy of a weight matrix W [R, C] (R % 16 == 0, C % kchunk == 0, kchunk % 32 == 0) for the kernel
 // above: block (kc, nt, ks) = 64 lanes x 8 elements at index ((kc * R/16 + nt) * KSC + ks), kc = kchunk-wide k chunk,
 // KSC = kchunk / 32, ks = 32-deep step inside it; lane l = 16g + cc, element e  <-  W[16nt + cc][kchunk kc + 32ks + k(g, e)]
@@ -568,4 +867,27 @@ extern "C" int vitpe_debug_tail2_census(const void* attn_out, const void* x_in, 
   VITPE_REQUIRE(census != nullptr);
   return tail2_launch(1, attn_out, x_in, Wp_packed, bp, gamma, beta, x_mid, mean2, rstd2, xn_out, W1_packed, b1, W2_packed, b2,
                       gp_out, h_out, out, mean_out, rstd_out, 1e-5f, 1e-5f, M, T2_D, HID, census, exp, stream);
+}
+
+// Backward of vitpe_block_tail2_fwd w.r.t. its inputs: du [M,HID] (fc1's weight gradient reads it), dx_mid [M,192], da [M,192]
+// (the attention backward's input); dgamma / dbeta of norm2 accumulated.  Weights as packed copies of the TRANSPOSES:
+// W2t_packed = pack(fc2.weight^T [HID,192], 192, 0), W1t_packed = pack(fc1.weight^T [192,HID], 32, 1),
+// WpT_packed = pack(attn.proj.weight^T [192,192], 192, 1).
+extern "C" int vitpe_block_tail2_bwd(int dtype, const void* dy, const void* gp, const void* W2t_packed, const void* W1t_packed,
+                                     const void* x_mid, const float* mean2, const float* rstd2, const float* gamma, void* du,
+                                     void* dx_mid, float* dgamma, float* dbeta, const void* WpT_packed, void* da, int M, int D,
+                                     int HID, hipStream_t stream) {
+  VITPE_REQUIRE(dy && gp && W2t_packed && W1t_packed && x_mid && mean2 && rstd2 && gamma && du && dx_mid && dgamma && dbeta &&
+                WpT_packed && da && M >= 0);
+  if (!vitpe_block_tail2_supported(dtype, D, HID)) return (int)hipErrorNotSupported;
+  if (M == 0) return 0;
+  Tail2BwdArgs a{};
+  a.dy = dy; a.gp = gp; a.xmid = x_mid; a.mean2 = mean2; a.rstd2 = rstd2; a.gamma = gamma; a.w2t = W2t_packed; a.w1t = W1t_packed;
+  a.wpt = WpT_packed; a.du = du; a.dxmid = dx_mid; a.da = da; a.dgamma = dgamma; a.dbeta = dbeta; a.M = M; a.HID = HID;
+  const int ntiles = (M + 15) / 16;
+  int grid;
+  if (ntiles <= 256 * 8) grid = (ntiles + 7) / 8;
+  else grid = 256 * ((ntiles + 256 * T2_WAVES - 1) / (256 * T2_WAVES));
+  hipLaunchKernelGGL(block_tail2_bwd_kernel, dim3(grid), dim3(T2_THREADS), 0, stream, a);
+  VITPE_CHECK_LAUNCH();
 }

@@ -81,6 +81,7 @@ class TrainEngine:
         # fragment-packed shadows, gelu'(u) saved instead of u); VITPE_TAIL2=0 keeps the first generation
         self.tail2 = (self.fuse_mlp and self.fuse_ln_bwd and self.fuse_tail and os.environ.get("VITPE_TAIL2", "1") == "1"
                       and K.block_tail2_supported(self.T, self.D, self.hid))
+        self.tail2_bwd = os.environ.get("VITPE_TAIL2_BWD", "1") == "1"   # (0: first-generation backward on the saved gelu')
         self._build_flat(lr, weight_decay, betas, eps)
         self._build_buffers()
         # gradient exchange in two buckets so the first overlaps the lower half of the backward pass:
@@ -119,6 +120,7 @@ class TrainEngine:
         self._st: Dict[int, torch.Tensor] = {}
         self._pk: Dict[int, torch.Tensor] = {}
         self._fr: Dict[int, torch.Tensor] = {}
+        self._frt: Dict[int, torch.Tensor] = {}
         self._gemm_weights: List[nn.Parameter] = []
         recs, off, tile0 = [], 0, 0
         def add(w, kind):
@@ -144,6 +146,10 @@ class TrainEngine:
                 spans.append((blk.attn.proj.weight, 2, add_frag(blk.attn.proj.weight, 2, 192)))
                 spans.append((blk.mlp.fc1.weight, 3, add_frag(blk.mlp.fc1.weight, 3, 192)))
                 spans.append((blk.mlp.fc2.weight, 3, add_frag(blk.mlp.fc2.weight, 3, 32)))
+                # the backward kernel's operands: packed TRANSPOSES (kinds 4 / 5)
+                spans.append((blk.mlp.fc2.weight, 4, add_frag(blk.mlp.fc2.weight, 4, 192)))
+                spans.append((blk.mlp.fc1.weight, 5, add_frag(blk.mlp.fc1.weight, 5, 32)))
+                spans.append((blk.attn.proj.weight, 5, add_frag(blk.attn.proj.weight, 5, 192)))
         self._shadow_flat = torch.empty(off, dtype=self.T, device=self.dev)
         for w, kind, o in spans:
             R, C = w.shape
@@ -151,8 +157,10 @@ class TrainEngine:
                 self._st[id(w)] = self._shadow_flat[o:o + R * C].view(C, R)
             elif kind == 1:
                 self._pk[id(w)] = self._shadow_flat[o:o + R * C].view(R, C)
-            else:
+            elif kind < 4:
                 self._fr[id(w)] = self._shadow_flat[o:o + R * C].view(R, C)
+            else:
+                self._frt[id(w)] = self._shadow_flat[o:o + R * C].view(C, R)
         import numpy as np
         rec = np.zeros(len(recs), dtype=np.dtype([("src", "<i8"), ("dst", "<i8"), ("R", "<i4"), ("C", "<i4"),
                                                    ("tile0", "<i4"), ("kind", "<i4"), ("HD", "<i4"), ("pad", "<i4")]))
@@ -183,6 +191,9 @@ class TrainEngine:
 
     def Fr(self, prm):  # fragment-major packed copy (block_tail2_fwd)
         return self._fr[id(prm)]
+
+    def Frt(self, prm):  # fragment-major packed copy of the transpose (block_tail2_bwd)
+        return self._frt[id(prm)]
 
     def refresh_shadows(self, cast_flat=True):
         if self.T == torch.bfloat16 and cast_flat:
@@ -354,6 +365,12 @@ class TrainEngine:
 
     def _block_tail_bwd(self, l, blk, a):
         M, D, G = self.M, self.D, self.Gr
+        if self.tail2 and self.tail2_bwd:
+            K.block_tail2_bwd(self.dx_out[l + 1].view(M, D), a["u"], self.Frt(blk.mlp.fc2.weight), self.Frt(blk.mlp.fc1.weight),
+                              a["xmid"].view(M, D), a["m2"], a["r2"], blk.norm2.weight.data, G(blk.norm2.weight),
+                              G(blk.norm2.bias), self.Frt(blk.attn.proj.weight), du=self.du_l[l],
+                              out=self.dx_mid[l].view(M, D), da=self.dtmp.view(M, D))
+            return
         K.block_tail_bwd(self.dx_out[l + 1].view(M, D), a["u"], self.St(blk.mlp.fc2.weight), self.St(blk.mlp.fc1.weight),
                          a["xmid"].view(M, D), a["m2"], a["r2"], blk.norm2.weight.data, G(blk.norm2.weight),
                          G(blk.norm2.bias), self.St(blk.attn.proj.weight), du=self.du_l[l], out=self.dx_mid[l].view(M, D),
@@ -754,7 +771,9 @@ class TrainEngine:
                                " (proj+residual+LN2+fc1+GELU+fc2+residual+stats)",
                                fns=[tail_f(l) for l in range(self.Lyr)], flop=tail_flop,
                                bytes=self._tail_bytes(fwd=True)))
-            probes.append(dict(name="block_tail_bwd", kernel="mlp_fwd_kernel<BWD> (gelu'+dgrad fc2/fc1+LN2 bwd+residual+dgrad proj)",
+            probes.append(dict(name="block_tail_bwd",
+                               kernel=("block_tail2_bwd_kernel" if self.tail2 and self.tail2_bwd else "mlp_fwd_kernel<BWD>") +
+                               " (gelu'+dgrad fc2/fc1+LN2 bwd+residual+dgrad proj)",
                                fns=[tail_b(l) for l in range(self.Lyr)], flop=tail_flop,
                                bytes=self._tail_bytes(fwd=False)))
             self._wgrad_group("all") if "all" not in self._wg_groups else None

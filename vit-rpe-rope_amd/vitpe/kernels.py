@@ -246,6 +246,24 @@ def block_tail_bwd(dy, u, w2t, w1t, x, mean, rstd, gamma, dgamma, dbeta, wpt, du
     return out, du, da
 
 
+def block_tail2_bwd(dy, gp, w2t_pk, w1t_pk, x_mid, mean2, rstd2, gamma, dgamma, dbeta, wpt_pk, du=None, out=None, da=None):
+    """Backward of block_tail2_fwd w.r.t. its inputs on packed TRANSPOSED weights (pack_weight_frags of fc2.weight^T
+    (192, natural), fc1.weight^T (32, phi), proj.weight^T (192, phi)) -> (dx_mid, du, da); dgamma / dbeta accumulated."""
+    require_device(dy, gp, w2t_pk, w1t_pk, x_mid, mean2, rstd2, gamma, dgamma, dbeta, wpt_pk, du, out, da)
+    M, D = dy.shape
+    HID = gp.shape[1]
+    assert gp.shape == (M, HID) and x_mid.shape == (M, D) and w2t_pk.numel() == HID * D and w1t_pk.numel() == HID * D
+    assert wpt_pk.numel() == D * D and dy.dtype == gp.dtype == w2t_pk.dtype == w1t_pk.dtype == x_mid.dtype == wpt_pk.dtype
+    _f32(gamma, "gamma"), _f32(dgamma, "dgamma"), _f32(dbeta, "dbeta"), _f32(mean2, "mean2"), _f32(rstd2, "rstd2")
+    du = du if du is not None else torch.empty_like(gp)
+    out = out if out is not None else torch.empty_like(dy)
+    da = da if da is not None else torch.empty_like(dy)
+    check(lib().vitpe_block_tail2_bwd(dtype_code(dy.dtype), ptr(dy), ptr(gp), ptr(w2t_pk), ptr(w1t_pk), ptr(x_mid), ptr(mean2),
+                                      ptr(rstd2), ptr(gamma), ptr(du), ptr(out), ptr(dgamma), ptr(dbeta), ptr(wpt_pk), ptr(da),
+                                      M, D, HID, stream_ptr()), "vitpe_block_tail2_bwd")
+    return out, du, da
+
+
 class _WgradProblem(ctypes.Structure):   # include/vitpe.h: vitpe_wgrad_problem
     _fields_ = [("dY", ctypes.c_void_p), ("X", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("dbias", ctypes.c_void_p),
                 ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("x_op", ctypes.c_int),
