@@ -1003,4 +1003,4 @@ extern "C" int vitpe_selftest_mma(int dtype, const void* A, const void* Bt, cons
   VITPE_CHECK_LAUNCH();
 }
 
-extern "C" int vitpe_abi_version(void) { return 2; }
+extern "C" int vitpe_abi_version(void) { return 3; }

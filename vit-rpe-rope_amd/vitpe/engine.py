@@ -139,7 +139,8 @@ class TrainEngine:
         for blk in self.model.blocks:
             for w in (blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight):
                 self._gemm_weights.append(w)
-                spans.append((w, 0, add(w, 0)))
+                if w is blk.attn.qkv.weight or not (self.tail2 and self.tail2_bwd):   # (the packed transposes replace these)
+                    spans.append((w, 0, add(w, 0)))
             if self.attn_fused:
                 spans.append((blk.attn.qkv.weight, 1, add(blk.attn.qkv.weight, 1)))
             if self.tail2:
