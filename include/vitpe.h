@@ -141,6 +141,12 @@ int vitpe_linear_ln(int dtype, int epi, const void* X, const float* gamma, const
 int vitpe_linear_lnbwd(int dtype, const void* dY, const void* Wt, void* dx, const void* x, const float* mean,
                        const float* rstd, const float* gamma, const void* dres, float* dgamma, float* dbeta,
                        int M, int K, vitpe_stream_t stream);
+/* vitpe_linear_lnbwd2: the same function on the wave-per-tile mapping of vitpe_block_tail2_*, with the weight given as
+ * Wt_packed = vitpe_pack_weight_frags(W^T [192,K], kchunk 192, phi 0), W = the Linear's weight [K,192] (attn.qkv.weight:
+ * K = 576).  bf16, K % 192 == 0; otherwise hipErrorNotSupported.                                                        */
+int vitpe_linear_lnbwd2(int dtype, const void* dY, const void* Wt_packed, void* dx, const void* x, const float* mean,
+                        const float* rstd, const float* gamma, const void* dres, float* dgamma, float* dbeta, int M,
+                        int K, vitpe_stream_t stream);
 /* vitpe_mlp_fwd: the whole MLP branch of a block in one kernel (vit.py:116-118,124 with timm Mlp):
  *   xn = LayerNorm(x) ; u = xn W1^T + b1 ; h = gelu(u) ; out = x + h W2^T + b2
  * x raw rows [M,192] with their LayerNorm statistics mean/rstd (e.g. vitpe_linear's stats output);

@@ -456,6 +456,31 @@ def test_block_tail2_backward_equals_first_generation_on_saved_derivative(K, M, 
     assert rel_err(da2.float().cpu(), dx2.float().cpu() @ q(wp, "bf16")) < 6e-3
 
 
+@pytest.mark.parametrize("M,Kd", [(650, 576), (33280, 576), (13, 192), (16 * 2048 + 16 * 40 + 3, 384)])
+def test_linear_lnbwd2_equals_first_generation(K, M, Kd):
+    """dx = dres + LayerNorm'(dY W) on the wave-per-tile mapping (packed W^T) against vitpe_linear_lnbwd and fp32 math."""
+    D, bf = 192, torch.bfloat16
+    x, g = rnd(M, D, seed=51), 1 + 0.1 * rnd(D, seed=52)
+    dy, dres = rnd(M, Kd, seed=53), rnd(M, D, seed=54)
+    w = rnd(Kd, D, seed=55, scale=0.06)                       # the Linear's weight [K, 192]
+    xd = dev(x, bf)
+    _, mean, rstd = K.layernorm_fwd(xd, dev(g), torch.zeros(D, device="cuda"))
+    dg2, db2 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    dx2 = K.linear_lnbwd2(dev(dy, bf), K.pack_weight_frags(dev(w.t().contiguous()), bf, 192, 0), xd, mean, rstd, dev(g),
+                          dev(dres, bf), dg2, db2)
+    dg1, db1 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    dx1 = K.linear_lnbwd(dev(dy, bf), dev(w.t().contiguous(), bf), xd, mean, rstd, dev(g), dev(dres, bf), dg1, db1)
+    assert rel_err(dx2.float().cpu(), dx1.float().cpu()) < 8e-3
+    assert rel_err(dg2.cpu(), dg1.cpu()) < 5e-3 and rel_err(db2.cpu(), db1.cpu()) < 5e-3
+    dxn = q(dy, "bf16") @ q(w, "bf16")
+    mu, rs = mean.cpu()[:, None], rstd.cpu()[:, None]
+    xhat = (q(x, "bf16") - mu) * rs
+    gy = dxn * g
+    ref = q(dres, "bf16") + rs * (gy - gy.mean(1, keepdim=True) - xhat * (gy * xhat).mean(1, keepdim=True))
+    assert rel_err(dx2.float().cpu(), ref) < 6e-3
+    assert rel_err(dg2.cpu(), (dxn * xhat).sum(0)) < 2e-3 and rel_err(db2.cpu(), dxn.sum(0)) < 2e-3
+
+
 def test_fused_mlp_unsupported_is_an_error(K):
     from vitpe._lib import VitpeError
     z = lambda *s: torch.zeros(*s, device="cuda")  # noqa: E731

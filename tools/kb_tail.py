@@ -71,6 +71,14 @@ def main():
                      ("block_tail2_fwd inference", lambda i: gen2(i, save=False, store_xn=False))):
         us = timeit(fn, rot=ROT)
         print(f"B={B} {name:30s} {us:8.2f} us = {flop / us / 1e6:7.1f} TF   {byts / us / 1e3:7.1f} GB/s (full-store bytes)", flush=True)
+    # dgrad qkv + LayerNorm1 backward
+    dq = [r(M, 3 * D).to(T) for _ in range(ROT)]
+    wq = r(3 * D, D) * 0.06
+    wqt, wqk = wq.t().contiguous().to(T), K.pack_weight_frags(wq.t().contiguous(), T, 192, 0)
+    for name, fn in (("linear_lnbwd  (gen 1) K=576", lambda i: K.linear_lnbwd(dq[i], wqt, xm[i], m2, r2, gam, dy[i], dg, db, out=dxm[i])),
+                     ("linear_lnbwd2 (gen 2) K=576", lambda i: K.linear_lnbwd2(dq[i], wqk, xm[i], m2, r2, gam, dy[i], dg, db, out=dxm[i]))):
+        us = timeit(fn, rot=ROT)
+        print(f"B={B} {name:30s} {us:8.2f} us = {2 * M * D * 3 * D / us / 1e6:7.1f} TF   {(M * 3 * D + 3 * M * D) * 2 / us / 1e3:7.1f} GB/s", flush=True)
     bb = (4 * M * D + 2 * M * HID) * 2
     for name, fn in (("block_tail_bwd  (gen 1, gp)", bwd1), ("block_tail2_bwd (gen 2)", bwd2)):
         us = timeit(fn, rot=ROT)

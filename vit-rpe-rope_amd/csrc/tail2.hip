@@ -543,6 +543,75 @@ VITPE_DEV float t2_colsum8(const float (&t)[8], int c) {
   return x + t2_dppc<0xB1>(x);                                                                               // quad_perm [1,0,3,2]
 }
 
+// LayerNorm backward + residual on a transposed 16-token tile: acc = gradient w.r.t. the LayerNorm's OUTPUT on entry,
+//   acc <- res + rstd (gy - mean_f(gy) - xhat mean_f(gy xhat)),  gy = acc gamma,  xhat = (x - mean) rstd
+// rounded to the bf16 values stored to `orow`; the tile's dgamma / dbeta column sums (rows past M masked by `valid`) go to
+// the workgroup's LDS accumulators sAcc[0..191 | 192..383].  xrow / rrow: this lane's LayerNorm-input / residual row + 4g.
+VITPE_DEV void t2_ln_backward(f32x4 (&acc)[T2_NT], const bf16* xrow, const bf16* rrow, float mean, float rstd,
+                              const float* sGam, float* sAcc, int c, int g, float valid, bf16* orow) {
+  constexpr int D = T2_D, NT = T2_NT;
+  bf16x4 xmv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) xmv[nt] = *reinterpret_cast<const bf16x4*>(xrow + 16 * nt);
+  const float invD = 1.0f / (float)D;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x4 gam = *reinterpret_cast<const f32x4*>(sGam + 16 * nt + 4 * g);
+    float tot[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float xhat = ((float)xmv[nt][r] - mean) * rstd;
+      const float dxn = acc[nt][r];
+      tot[r] = dxn * xhat * valid;       // dgamma / dbeta contributions (rows past M masked)
+      tot[4 + r] = dxn * valid;
+      const float gy = dxn * gam[r];
+      s1 += gy;
+      s2 = fmaf(gy, xhat, s2);
+    }
+    // column sums over the tile's 16 tokens: even lane c of every row ends with total (c >> 1): one LDS atomic per tile
+    const float sel = t2_colsum8(tot, c);
+    if (!(c & 1)) atomicAdd(&sAcc[(c < 8 ? 0 : D - 4) + 16 * nt + 4 * g + (c >> 1)], sel);
+  }
+  const float m1 = t2_xg_sum(s1) * invD, m2 = t2_xg_sum(s2) * invD;
+  bf16x4 rv[NT];                                   // the residual rows
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) rv[nt] = *reinterpret_cast<const bf16x4*>(rrow + 16 * nt);
+  // second pass: gy and xhat are recomputed from the packed rows (keeping 48 fp32 xhat values alive across the row sums
+  // is what spilled); the empty asm stops the compiler from re-using the first pass's conversions
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    __builtin_amdgcn_sched_barrier(0);
+    uint2 xw = __builtin_bit_cast(uint2, xmv[nt]);
+    asm volatile("" : "+v"(xw.x), "+v"(xw.y));
+    const bf16x4 xb = __builtin_bit_cast(bf16x4, xw);
+    const f32x4 gam = *reinterpret_cast<const f32x4*>(sGam + 16 * nt + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float xhat = ((float)xb[r] - mean) * rstd;
+      const float gy = acc[nt][r] * gam[r];
+      acc[nt][r] = to_f32(from_f32<bf16>(fmaf(rstd, gy - m1 - xhat * m2, (float)rv[nt][r])));   // as stored
+    }
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; nt += 2) t2_store_pair<false>(orow, nt, g, acc[nt], acc[nt + 1]);
+}
+
+// the last of the workgroup's `nactive` compute waves to arrive hands the LDS column sums to the global accumulators
+VITPE_DEV void t2_flush_colsums(float* sAcc, int* sFin, int nactive, int lane, float* dgamma, float* dbeta) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  int fin = 0;
+  if (lane == 0) fin = atomicAdd(sFin, 1);
+  fin = __builtin_amdgcn_readfirstlane(fin);
+  if (fin == nactive - 1) {
+    for (int i = lane; i < T2_D; i += 64) {
+      atomicAdd(dgamma + i, __hip_atomic_load(&sAcc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      atomicAdd(dbeta + i, __hip_atomic_load(&sAcc[T2_D + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    }
+  }
+}
+
 __global__ __launch_bounds__(T2_THREADS) void block_tail2_bwd_kernel(Tail2BwdArgs a) {
   using T = bf16;
   constexpr int D = T2_D, NT = T2_NT, KS = T2_KS;
@@ -687,65 +756,10 @@ __global__ __launch_bounds__(T2_THREADS) void block_tail2_bwd_kernel(Tail2BwdArg
     t2_step<false, true, 0, 0, RB>(w2b, w2b + NT * 512, bf, aX, hQ, acc2, [&]() {});                                  // F2_last
     signal_done(nchunk + 1);
   }
-  // LayerNorm input rows (only now are there registers for them)
-  bf16x4 xmv[NT];
-  {
-    const T* xr = reinterpret_cast<const T*>(a.xmid) + (size_t)rowc * D + 4 * g;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) xmv[nt] = *reinterpret_cast<const bf16x4*>(xr + 16 * nt);
-  }
-  const float mean = a.mean2[rowc], rstd = a.rstd2[rowc];
-
-  // ---- LayerNorm2 backward + residual: dx_mid = dy + rstd (gy - mean_f(gy) - xhat mean_f(gy xhat)), gy = dxn gamma ----------
-  const float invD = 1.0f / (float)D;
-  float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    __builtin_amdgcn_sched_barrier(0);
-    const f32x4 gam = *reinterpret_cast<const f32x4*>(sGam + 16 * nt + 4 * g);
-    float tot[8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float xhat = ((float)xmv[nt][r] - mean) * rstd;
-      const float dxn = acc2[nt][r];
-      tot[r] = dxn * xhat * valid;       // dgamma / dbeta contributions (rows past M masked)
-      tot[4 + r] = dxn * valid;
-      const float gy = dxn * gam[r];
-      s1 += gy;
-      s2 = fmaf(gy, xhat, s2);
-    }
-    // column sums over the tile's 16 tokens: even lane c of every row ends with total (c >> 1): one LDS atomic per tile
-    const float sel = t2_colsum8(tot, c);
-    if (!(c & 1)) atomicAdd(&sAcc[(c < 8 ? 0 : D - 4) + 16 * nt + 4 * g + (c >> 1)], sel);
-  }
-  const float m1 = t2_xg_sum(s1) * invD, m2 = t2_xg_sum(s2) * invD;
-  bf16x4 dyv[NT];                                  // the residual rows
-  {
-    const T* dr = reinterpret_cast<const T*>(a.dy) + (size_t)rowc * D + 4 * g;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) dyv[nt] = *reinterpret_cast<const bf16x4*>(dr + 16 * nt);
-  }
-  // second pass: gy and xhat are recomputed from the packed rows (keeping 48 fp32 xhat values alive across the row sums
-  // is what spilled); the empty asm stops the compiler from re-using the first pass's conversions
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    __builtin_amdgcn_sched_barrier(0);
-    uint2 xw = __builtin_bit_cast(uint2, xmv[nt]);
-    asm volatile("" : "+v"(xw.x), "+v"(xw.y));
-    const bf16x4 xb = __builtin_bit_cast(bf16x4, xw);
-    const f32x4 gam = *reinterpret_cast<const f32x4*>(sGam + 16 * nt + 4 * g);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float xhat = ((float)xb[r] - mean) * rstd;
-      const float gy = acc2[nt][r] * gam[r];
-      acc2[nt][r] = to_f32(from_f32<T>(fmaf(rstd, gy - m1 - xhat * m2, (float)dyv[nt][r])));   // as stored
-    }
-  }
-  {
-    T* const dxr = reinterpret_cast<T*>(a.dxmid) + (size_t)rowc * D;
-#pragma unroll
-    for (int nt = 0; nt < NT; nt += 2) t2_store_pair<false>(dxr, nt, g, acc2[nt], acc2[nt + 1]);
-  }
+  // ---- LayerNorm2 backward + residual: dx_mid = dy + LayerNorm2'(dxn) ------------------------------------------------------------
+  t2_ln_backward(acc2, reinterpret_cast<const T*>(a.xmid) + (size_t)rowc * D + 4 * g,
+                 reinterpret_cast<const T*>(a.dy) + (size_t)rowc * D + 4 * g, a.mean2[rowc], a.rstd2[rowc], sGam, sAcc, c, g,
+                 valid, reinterpret_cast<T*>(a.dxmid) + (size_t)rowc * D);
   // ---- da = dx_mid Wp ----------------------------------------------------------------------------------------------------------
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) bf[ks] = acc_to_frag<T>(acc2[2 * ks], acc2[2 * ks + 1]);
@@ -759,17 +773,111 @@ __global__ __launch_bounds__(T2_THREADS) void block_tail2_bwd_kernel(Tail2BwdArg
 #pragma unroll
     for (int nt = 0; nt < NT; nt += 2) t2_store_pair<false>(dar, nt, g, accA[nt], accA[nt + 1]);
   }
-  // ---- the last wave of the workgroup hands the column sums to the global accumulators ----------------------------------------
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  int fin = 0;
-  if (lane == 0) fin = atomicAdd(&sFin, 1);
-  fin = __builtin_amdgcn_readfirstlane(fin);
-  if (fin == ntile_wg - 1) {
-    for (int i = lane; i < D; i += 64) {
-      atomicAdd(a.dgamma + i, __hip_atomic_load(&sAcc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-      atomicAdd(a.dbeta + i, __hip_atomic_load(&sAcc[D + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+  t2_flush_colsums(sAcc, &sFin, ntile_wg, lane, a.dgamma, a.dbeta);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dx = dres + LayerNorm'(dY Wt^T): the data gradient of a Linear whose input is a LayerNorm output, that LayerNorm's
+// backward, and the residual add (attn.qkv: dY = d_qkv [M,576], LayerNorm1, dres = d x_mid) -- the wave-per-tile mapping of
+// the kernels above.  Wt packed = pack(weight^T [192, K], kchunk 192, natural): K / 192 slabs of 72 fragments, two LDS
+// buffers, the two loader waves each move half a slab; a compute wave loads its 16 dY rows as B fragments straight from
+// global, one 192-wide k chunk ahead of the product.
+struct LnBwd2Args {
+  const void* dy;       // [M,K]
+  const void* wt;       // pack(W^T [192,K], 192, natural)
+  const void* x;        // [M,192] LayerNorm input rows
+  const float* mean;
+  const float* rstd;
+  const float* gamma;
+  const void* dres;     // [M,192] residual gradient
+  void* dx;             // [M,192] out
+  float* dgamma;
+  float* dbeta;
+  int M, K;
+};
+
+__global__ __launch_bounds__(T2_THREADS) void ln_bwd2_kernel(LnBwd2Args a) {
+  using T = bf16;
+  constexpr int D = T2_D, NT = T2_NT, KS = T2_KS, SLF = NT * KS;    // 72 fragments per slab
+  __shared__ __attribute__((aligned(16))) T sW[2 * SLF * 512];
+  __shared__ __attribute__((aligned(16))) float sGam[T2_D];
+  __shared__ float sAcc[2 * T2_D];
+  __shared__ int sReady[T2_NFLAG], sDone[T2_NFLAG], sFin;
+
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int K = a.K, nslab = K / D;
+  const int ntiles = (a.M + 15) / 16, base = ntiles / (int)gridDim.x, rem = ntiles % (int)gridDim.x;
+  const int tile0 = (int)blockIdx.x * base + min((int)blockIdx.x, rem), ntile_wg = base + ((int)blockIdx.x < rem ? 1 : 0);
+  const bool active = wave < ntile_wg;
+  const int row = 16 * (tile0 + wave) + c;
+  const int rowc = min(row, a.M - 1);
+  const float valid = row < a.M ? 1.0f : 0.0f;
+
+  if (threadIdx.x < T2_NFLAG) { sReady[threadIdx.x] = 0; sDone[threadIdx.x] = 0; }
+  if (threadIdx.x == 0) sFin = 0;
+  for (int i = threadIdx.x; i < 2 * D; i += T2_THREADS) sAcc[i] = 0.f;
+  for (int i = threadIdx.x; i < D; i += T2_THREADS) sGam[i] = a.gamma[i];
+
+  if (wave >= T2_WAVES) {      // loaders: half a slab each (36 pieces), slab s -> buffer s & 1
+    const int half = wave == T2_WAVES ? 0 : SLF / 2;
+    auto dma_half = [&](int sl) {
+#pragma unroll
+      for (int f = 0; f < SLF / 2; ++f) {
+        const T* src = reinterpret_cast<const T*>(a.wt) + ((size_t)sl * SLF + half + f) * 512 + lane * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(sW + ((sl & 1) * SLF + half + f) * 512), 16, 0, 0);
+      }
+    };
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    asm volatile("s_barrier" ::: "memory");
+    dma_half(0);
+    if (nslab > 1) dma_half(1);
+    for (int sl = 0; sl < nslab; ++sl) {
+      if (sl + 1 < nslab) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");   // only slab sl + 1's pieces may be in flight
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      asm volatile("" ::: "memory");
+      if (lane == 0) atomicAdd(&sReady[sl], 1);
+      if (sl + 2 < nslab) {
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sDone[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < ntile_wg)
+          __builtin_amdgcn_s_sleep(2);
+        asm volatile("" ::: "memory");
+        dma_half(sl + 2);
+      }
     }
+    return;
   }
+  __builtin_amdgcn_s_waitcnt(0x0070);
+  asm volatile("s_barrier" ::: "memory");
+  if (!active) return;
+
+  const T* const dr = reinterpret_cast<const T*>(a.dy) + (size_t)rowc * K + 8 * g;
+  Frag<T> bfa[KS], bfb[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) bfa[ks] = ld_frag(dr + 32 * ks);
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto chunk = [&](int sl, const Frag<T> (&cur)[KS], Frag<T> (&nxt)[KS]) {
+    if (sl + 1 < nslab) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) nxt[ks] = ld_frag(dr + (sl + 1) * D + 32 * ks);
+    }
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sReady[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < 2)
+      __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+    t2_gemm<NT, KS, 12>(sW + (sl & 1) * SLF * 512 + lane * 8, cur, acc);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) atomicAdd(&sDone[sl], 1);
+  };
+  for (int sl = 0; sl < nslab; sl += 2) {
+    chunk(sl, bfa, bfb);
+    if (sl + 1 < nslab) chunk(sl + 1, bfb, bfa);
+  }
+  t2_ln_backward(acc, reinterpret_cast<const T*>(a.x) + (size_t)rowc * D + 4 * g,
+                 reinterpret_cast<const T*>(a.dres) + (size_t)rowc * D + 4 * g, a.mean[rowc], a.rstd[rowc], sGam, sAcc, c, g,
+                 valid, reinterpret_cast<T*>(a.dx) + (size_t)rowc * D);
+  t2_flush_colsums(sAcc, &sFin, ntile_wg, lane, a.dgamma, a.dbeta);
 }
 
 // Fragment-major packed copy of a weight matrix W [R, C] (R % 16 == 0, C % kchunk == 0, kchunk % 32 == 0) for the kernel
@@ -889,5 +997,24 @@ extern "C" int vitpe_block_tail2_bwd(int dtype, const void* dy, const void* gp, 
   if (ntiles <= 256 * 8) grid = (ntiles + 7) / 8;
   else grid = 256 * ((ntiles + 256 * T2_WAVES - 1) / (256 * T2_WAVES));
   hipLaunchKernelGGL(block_tail2_bwd_kernel, dim3(grid), dim3(T2_THREADS), 0, stream, a);
+  VITPE_CHECK_LAUNCH();
+}
+
+// dx = dres + LayerNorm'(dY W) with Wt_packed = pack(W^T [192,K], kchunk 192, natural) (W = the Linear's weight [K,192], e.g.
+// attn.qkv.weight): vitpe_linear_lnbwd on the wave-per-tile mapping.  bf16, K % 192 == 0, K <= 192 * 24.
+extern "C" int vitpe_linear_lnbwd2(int dtype, const void* dY, const void* Wt_packed, void* dx, const void* x, const float* mean,
+                                   const float* rstd, const float* gamma, const void* dres, float* dgamma, float* dbeta, int M,
+                                   int K, hipStream_t stream) {
+  VITPE_REQUIRE(dY && Wt_packed && dx && x && mean && rstd && gamma && dres && dgamma && dbeta && M >= 0);
+  if (dtype != 1 || K <= 0 || K % T2_D != 0 || K / T2_D >= T2_NFLAG) return (int)hipErrorNotSupported;
+  if (M == 0) return 0;
+  LnBwd2Args a{};
+  a.dy = dY; a.wt = Wt_packed; a.x = x; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.dres = dres; a.dx = dx;
+  a.dgamma = dgamma; a.dbeta = dbeta; a.M = M; a.K = K;
+  const int ntiles = (M + 15) / 16;
+  int grid;
+  if (ntiles <= 256 * 8) grid = (ntiles + 7) / 8;
+  else grid = 256 * ((ntiles + 256 * T2_WAVES - 1) / (256 * T2_WAVES));
+  hipLaunchKernelGGL(ln_bwd2_kernel, dim3(grid), dim3(T2_THREADS), 0, stream, a);
   VITPE_CHECK_LAUNCH();
 }

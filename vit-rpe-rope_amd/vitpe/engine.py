@@ -82,6 +82,9 @@ class TrainEngine:
         self.tail2 = (self.fuse_mlp and self.fuse_ln_bwd and self.fuse_tail and os.environ.get("VITPE_TAIL2", "1") == "1"
                       and K.block_tail2_supported(self.T, self.D, self.hid))
         self.tail2_bwd = os.environ.get("VITPE_TAIL2_BWD", "1") == "1"   # (0: first-generation backward on the saved gelu')
+        # qkv data gradient + LayerNorm1 backward on the same mapping: correct but SLOWER than the panel kernel (40 vs 32 us:
+        # 216 LDS-DMA pieces per 9 tiles keep the two loader waves busy for longer than the product takes) -- opt-in
+        self.lnbwd2 = self.tail2 and self.tail2_bwd and os.environ.get("VITPE_LNBWD2", "0") == "1"
         self._build_flat(lr, weight_decay, betas, eps)
         self._build_buffers()
         # gradient exchange in two buckets so the first overlaps the lower half of the backward pass:
@@ -139,18 +142,20 @@ class TrainEngine:
         for blk in self.model.blocks:
             for w in (blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight):
                 self._gemm_weights.append(w)
-                if w is blk.attn.qkv.weight or not (self.tail2 and self.tail2_bwd):   # (the packed transposes replace these)
-                    spans.append((w, 0, add(w, 0)))
+                if not (self.tail2 and self.tail2_bwd) or (w is blk.attn.qkv.weight and not self.lnbwd2):
+                    spans.append((w, 0, add(w, 0)))                    # (the packed transposes below replace the others)
             if self.attn_fused:
                 spans.append((blk.attn.qkv.weight, 1, add(blk.attn.qkv.weight, 1)))
             if self.tail2:
                 spans.append((blk.attn.proj.weight, 2, add_frag(blk.attn.proj.weight, 2, 192)))
                 spans.append((blk.mlp.fc1.weight, 3, add_frag(blk.mlp.fc1.weight, 3, 192)))
                 spans.append((blk.mlp.fc2.weight, 3, add_frag(blk.mlp.fc2.weight, 3, 32)))
-                # the backward kernel's operands: packed TRANSPOSES (kinds 4 / 5)
-                spans.append((blk.mlp.fc2.weight, 4, add_frag(blk.mlp.fc2.weight, 4, 192)))
-                spans.append((blk.mlp.fc1.weight, 5, add_frag(blk.mlp.fc1.weight, 5, 32)))
-                spans.append((blk.attn.proj.weight, 5, add_frag(blk.attn.proj.weight, 5, 192)))
+                if self.tail2_bwd:   # the backward kernels' operands: packed TRANSPOSES (kinds 4 / 5)
+                    spans.append((blk.mlp.fc2.weight, 4, add_frag(blk.mlp.fc2.weight, 4, 192)))
+                    spans.append((blk.mlp.fc1.weight, 5, add_frag(blk.mlp.fc1.weight, 5, 32)))
+                    spans.append((blk.attn.proj.weight, 5, add_frag(blk.attn.proj.weight, 5, 192)))
+                    if self.lnbwd2:
+                        spans.append((blk.attn.qkv.weight, 4, add_frag(blk.attn.qkv.weight, 4, 192)))
         self._shadow_flat = torch.empty(off, dtype=self.T, device=self.dev)
         for w, kind, o in spans:
             R, C = w.shape
@@ -506,7 +511,11 @@ class TrainEngine:
                 K.attention_core_bwd(self.qkv_l[l], self.dtmp, self.H, self.pe, out=dqkv, **self.pe_grads)
             e_dq = ev()
             self._wgrad(e_dq, lambda: K.gemm_tn(dqkv.view(M, 3 * D), a["xn1"].view(M, D), G(blk.attn.qkv.weight), None))
-            if self.fuse_ln_bwd:   # data gradient of qkv + LayerNorm1 backward + residual add in one kernel
+            if self.fuse_ln_bwd and self.lnbwd2:   # ... on the wave-per-tile mapping, packed qkv.weight^T (opt-in)
+                K.linear_lnbwd2(dqkv.view(M, 3 * D), self.Frt(blk.attn.qkv.weight), self.x[l].view(M, D), a["m1"],
+                                a["r1"], blk.norm1.weight.data, dm, G(blk.norm1.weight), G(blk.norm1.bias),
+                                out=self.dx_out[l].view(M, D))
+            elif self.fuse_ln_bwd:   # data gradient of qkv + LayerNorm1 backward + residual add in one kernel
                 K.linear_lnbwd(dqkv.view(M, 3 * D), self.St(blk.attn.qkv.weight), self.x[l].view(M, D), a["m1"],
                                a["r1"], blk.norm1.weight.data, dm, G(blk.norm1.weight), G(blk.norm1.bias),
                                out=self.dx_out[l].view(M, D))

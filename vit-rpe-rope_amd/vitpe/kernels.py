@@ -82,6 +82,19 @@ def linear_lnbwd(dy, wt, x, mean, rstd, gamma, dres, dgamma, dbeta, out=None):
     return dx
 
 
+def linear_lnbwd2(dy, wt_pk, x, mean, rstd, gamma, dres, dgamma, dbeta, out=None):
+    """linear_lnbwd on the wave-per-tile mapping; wt_pk = pack_weight_frags(weight^T [192,K], dtype, 192, 0)."""
+    require_device(dy, wt_pk, x, mean, rstd, gamma, dres, dgamma, dbeta, out)
+    M, K = dy.shape
+    assert wt_pk.numel() == 192 * K and x.shape[-1] == 192 and dy.dtype == wt_pk.dtype == x.dtype == dres.dtype
+    _f32(gamma, "gamma"), _f32(dgamma, "dgamma"), _f32(dbeta, "dbeta"), _f32(mean, "mean"), _f32(rstd, "rstd")
+    dx = out if out is not None else torch.empty((M, 192), dtype=dy.dtype, device=dy.device)
+    check(lib().vitpe_linear_lnbwd2(dtype_code(dy.dtype), ptr(dy), ptr(wt_pk), ptr(dx), ptr(x), ptr(mean), ptr(rstd),
+                                    ptr(gamma), ptr(dres), ptr(dgamma), ptr(dbeta), M, K, stream_ptr()),
+          "vitpe_linear_lnbwd2")
+    return dx
+
+
 def patch_embed_gemm(patches, w, bias, cls, ape, B, P, out=None):
     """tokens[B,P+1,N] from unfolded patches [B*P,K] (vit.py:248-258)."""
     require_device(patches, w, bias, cls, ape, out)
