@@ -572,6 +572,9 @@ VITPE_DEV void t2_ln_backward(f32x4 (&acc)[T2_NT], const bf16* xrow, const bf16*
     }
     // column sums over the tile's 16 tokens: even lane c of every row ends with total (c >> 1): one LDS atomic per tile
     const float sel = t2_colsum8(tot, c);
+    // (the conditional atomic ends a basic block; without this pin the compiler sinks the whole s1 / s2 chains past all
+    //  twelve blocks and keeps the 48 xhat values alive for them: 36 spilled registers)
+    asm volatile("" : "+v"(s1), "+v"(s2));
     if (!(c & 1)) atomicAdd(&sAcc[(c < 8 ? 0 : D - 4) + 16 * nt + 4 * g + (c >> 1)], sel);
   }
   const float m1 = t2_xg_sum(s1) * invD, m2 = t2_xg_sum(s2) * invD;
