@@ -620,6 +620,9 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, 3) void attn_bwd_reg_kernel(At
       acc[1] = x1 * sv + x2 * cv;
     }
     dst = acc_to_frag<T>(acc[0] * sc, acc[1] * sc);
+    // pin the packed fragment here: left alone the compiler sinks the conversion to the fragment's first use (after the
+    // barrier) and carries -- and spills -- the fp32 accumulators, twice the registers
+    asm volatile("" : "+v"(dst.v));
   };
   // Transposition on the matrix core.  A swapped fragment f[tt] holds X[token 16tt + c][feature phi(g, t)] (phi = the
   // acc_to_frag order: t < 4 -> 4g + t, t >= 4 -> 16 + 4g + t - 4); multiplied by the 0/1 selection matrix E_nt

@@ -82,9 +82,9 @@ class TrainEngine:
         self.tail2 = (self.fuse_mlp and self.fuse_ln_bwd and self.fuse_tail and os.environ.get("VITPE_TAIL2", "1") == "1"
                       and K.block_tail2_supported(self.T, self.D, self.hid))
         self.tail2_bwd = os.environ.get("VITPE_TAIL2_BWD", "1") == "1"   # (0: first-generation backward on the saved gelu')
-        # qkv data gradient + LayerNorm1 backward on the same mapping: correct but SLOWER than the panel kernel (40 vs 32 us:
-        # 216 LDS-DMA pieces per 9 tiles keep the two loader waves busy for longer than the product takes) -- opt-in
-        self.lnbwd2 = self.tail2 and self.tail2_bwd and os.environ.get("VITPE_LNBWD2", "0") == "1"
+        # qkv data gradient + LayerNorm1 backward on the same mapping (29.5 vs 31.4 us for the panel kernel; VITPE_LNBWD2=0:
+        # the panel kernel on the transposed shadow)
+        self.lnbwd2 = self.tail2 and self.tail2_bwd and os.environ.get("VITPE_LNBWD2", "1") == "1"
         self._build_flat(lr, weight_decay, betas, eps)
         self._build_buffers()
         # gradient exchange in two buckets so the first overlaps the lower half of the backward pass:
