@@ -30,7 +30,7 @@ PROBES = {
     "block_tail_fwd": ["block_tail2_fwd_kernel"],
     "block_tail_bwd": ["block_tail2_bwd_kernel"],
     "wgrad_group": ["wgrad_group_kernel"],
-    "dgrad_qkv_ln1_bwd": ["gemm_panel_kernel"],
+    "dgrad_qkv_ln1_bwd": ["ln_bwd2_kernel"],
     "head_step": ["head_step_kernel"],
     "patch_embed": ["patch_embed_kernel"],
     "adamw": ["adamw_kernel"],
@@ -38,6 +38,7 @@ PROBES = {
 }
 # first-generation block-tail kernels (when the second generation does not run): mangled vs demangled spelling
 FALLBACK = {
+    "dgrad_qkv_ln1_bwd": [["gemm_panel_kernel"]],
     "block_tail_fwd": [["mlp_fwd_kernelIDF16bLi0E"], ["mlp_fwd_kernel<", "0, true"]],
     "block_tail_bwd": [["vitpe::mlp_fwd_kernel<"], ["mlp_fwd_kernelIDF16bLi1E"]],
 }
@@ -109,8 +110,10 @@ def main():
             v = med(sq, k)
             if v is not None:
                 ent[k] = v
+        # SQ_VALU_MFMA_BUSY_CYCLES counts SIMD-cycles (16 per 16x16x32 bf16 MFMA, summed over the chip); SQ_BUSY_CYCLES is
+        # summed over the 32 shader engines, each with 32 SIMDs: SIMD-cycles available = SQ_BUSY_CYCLES x 32
         if busy and mf is not None:
-            ent["mfma_pipe_busy_frac"] = round(mf / busy, 4)
+            ent["mfma_pipe_busy_frac"] = round(mf / (busy * 32.0), 4)
         lc, la = med(sq, "SQ_LDS_BANK_CONFLICT"), med(sq, "SQ_LDS_IDX_ACTIVE")
         if la and lc is not None:
             ent["lds_bank_conflict_frac"] = round(lc / la, 4)

@@ -786,6 +786,16 @@ class TrainEngine:
                                " (gelu'+dgrad fc2/fc1+LN2 bwd+residual+dgrad proj)",
                                fns=[tail_b(l) for l in range(self.Lyr)], flop=tail_flop,
                                bytes=self._tail_bytes(fwd=False)))
+            if self.lnbwd2:
+                def dg(l):
+                    blk, a = mdl.blocks[l], self.act[l]
+                    return lambda: K.linear_lnbwd2(self.dqkv_l[l].view(M, 3 * D), self.Frt(blk.attn.qkv.weight),
+                                                   self.x[l].view(M, D), a["m1"], a["r1"], blk.norm1.weight.data,
+                                                   self.dx_mid[l].view(M, D), self.Gr(blk.norm1.weight), self.Gr(blk.norm1.bias),
+                                                   out=self.dx_out[l].view(M, D))
+                probes.append(dict(name="dgrad_qkv_ln1_bwd", kernel="ln_bwd2_kernel (dgrad qkv + LayerNorm1 backward + residual)",
+                                   fns=[dg(l) for l in range(self.Lyr)], flop=2 * M * D * 3 * D,
+                                   bytes=(3 * M * D + 3 * M * D) * es))     # d_qkv, x, d x_mid in; d x out
             self._wgrad_group("all") if "all" not in self._wg_groups else None
             wg_flop = sum(2 * dy.shape[0] * dy.shape[1] * x.shape[1] for grp in self._wg_groups["all"] for dy, x, _, _ in grp.keep)
             wg_bytes = sum((dy.numel() + x.numel()) * es + dw.numel() * 4 for grp in self._wg_groups["all"] for dy, x, dw, _ in grp.keep)
