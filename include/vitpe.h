@@ -358,11 +358,15 @@ int vitpe_adamw_step(float* p, float* g, float* m, float* v, void* shadow_bf16, 
 int vitpe_cast(int dtype, const float* src, void* dst, long long n, vitpe_stream_t stream);
 int vitpe_transpose_cast(int dtype, const float* src, void* dst, int R, int C, vitpe_stream_t stream);
 /* every weight shadow of the model in one launch.  desc: device array of ndesc records
- * {int64 src_off (elements into flat), int64 dst_off (elements into dst_base), int32 R, C, tile0,
- *  kind (0 = transpose, 1 = vitpe_pack_qkv_weights layout), HD, pad}; tile0 = running sum of
- * ceil(R/32)*ceil(C/32); total_tiles = that sum over all records.                               */
+ * {int64 src_off (elements into flat), int64 dst_off, int64 dst_off2 (elements into dst_base), int32 R, C, tile0,
+ *  kind, HD, kind2, HD2, pad}: the fp32 matrix [R,C] at src_off is written as shadow `kind` at dst_off and, when
+ *  kind2 >= 0, as shadow `kind2` at dst_off2 (one load of the source tile for both).  kind: 0 = transpose,
+ *  1 = vitpe_pack_qkv_weights layout (HD = head dim), 2 / 3 = vitpe_pack_weight_frags of the matrix (natural / phi k
+ *  order, HD = k chunk), 4 / 5 = vitpe_pack_weight_frags of its TRANSPOSE.  tile0 = running sum of
+ *  ceil(R/32)*ceil(C/32); total_tiles = that sum over all records; tile_map (nullable): uint16[total_tiles], the record
+ *  index of every 32x32 tile (without it each workgroup scans the records).                                        */
 int vitpe_refresh_shadows(int dtype, const float* flat, void* dst_base, const void* desc, int ndesc,
-                          int total_tiles, vitpe_stream_t stream);
+                          int total_tiles, const unsigned short* tile_map, vitpe_stream_t stream);
 
 /* Self-tests and residency / phase-census instrumentation are NOT part of this boundary: include/vitpe_debug.h. */
 

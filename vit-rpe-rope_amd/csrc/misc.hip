@@ -661,68 +661,79 @@ __global__ void transpose_cast_kernel(const float* __restrict__ src, T* __restri
 // each workgroup handles one 32x32 tile.  kind 0: dst[c][r] = src[r][c] (transposed shadow for the
 // data-gradient GEMMs); kind 1: fragment-major packing of attn.qkv.weight (see pack_qkv_kernel); kind 2 / 3: the
 // fragment-major packing of tail2.hip (natural / acc_to_frag k order, HD field = k chunk); kind 4 / 5: the same of W^T.
-struct ShadowDesc { long long src_off, dst_off; int R, C, tile0, kind, HD, pad; };
+// A descriptor may name a SECOND shadow of the same matrix (kind2 >= 0): the source tile is loaded once for both (a weight
+// and its transpose packs, the qkv pack and its transposed pack).  tile_map[block] = descriptor index (host-built; without
+// it every block scans the descriptor list -- 48 dependent-latency loads per block were most of this kernel's time).
+struct ShadowDesc { long long src_off, dst_off, dst_off2; int R, C, tile0, kind, HD, kind2, HD2, pad; };
 
 template <typename T>
 __global__ __launch_bounds__(256) void refresh_shadows_kernel(const float* __restrict__ flat, T* __restrict__ dst_base,
-                                                              const ShadowDesc* __restrict__ desc, int ndesc) {
+                                                              const ShadowDesc* __restrict__ desc, int ndesc,
+                                                              const unsigned short* __restrict__ tile_map) {
   __shared__ float tile[32][33];
   int d = 0;
-  for (int i = 1; i < ndesc; ++i)
-    if ((int)blockIdx.x >= desc[i].tile0) d = i;   // wave-uniform scan of a handful of descriptors
+  if (tile_map != nullptr) {
+    d = tile_map[blockIdx.x];
+  } else {
+    for (int i = 1; i < ndesc; ++i)
+      if ((int)blockIdx.x >= desc[i].tile0) d = i;   // wave-uniform scan of a handful of descriptors
+  }
   const ShadowDesc ds = desc[d];
   const int t = blockIdx.x - ds.tile0;
   const int tc = (ds.C + 31) / 32;
   const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
   const float* src = flat + ds.src_off;
-  T* dst = dst_base + ds.dst_off;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int i = ty; i < 32; i += 8) {
     const int r = r0 + i, c = c0 + tx;
     tile[i][tx] = (r < ds.R && c < ds.C) ? src[(size_t)r * ds.C + c] : 0.f;
   }
   __syncthreads();
-  if (ds.kind == 0) {
-    for (int i = ty; i < 32; i += 8) {
-      const int c = c0 + i, r = r0 + tx;
-      if (c < ds.C && r < ds.R) dst[(size_t)c * ds.R + r] = from_f32<T>(tile[tx][i]);
-    }
-  } else if (ds.kind >= 2) {
-    // vitpe_pack_weight_frags layout (tail2.hip): HD field = k chunk; kinds 2 / 3 pack W itself in natural / acc_to_frag
-    // k order, kinds 4 / 5 pack W^T (the backward kernel's operands) the same two ways.
-    // A 32x32 tile is exactly two 1-KB fragments (output tiles p0/16, p0/16 + 1 of one k step): every thread writes 4
-    // consecutive destination elements (both dimensions are multiples of 32 for these matrices).
-    const bool tr = ds.kind >= 4, phi = (ds.kind & 1) != 0;
-    const int PR = tr ? ds.C : ds.R;                       // rows of the packed matrix
-    const int p0 = tr ? c0 : r0, k0 = tr ? r0 : c0;        // its row / column origin of this tile
-    const int kch = ds.HD, KSC = kch / 32, NTr = PR / 16;
-    const int kc = k0 / kch, ks = (k0 % kch) / 32;
-    const int d = threadIdx.x * 4, frag = d >> 9, within = d & 511, l = within >> 3, e0 = within & 7;
-    const int nt = p0 / 16 + frag, cc = l & 15, g = l >> 4;
-    if (16 * nt < PR) {
-      float v[4];
+  auto emit = [&](int kind, T* dst, int hd) {
+    if (kind == 0) {
+      for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < ds.C && r < ds.R) dst[(size_t)c * ds.R + r] = from_f32<T>(tile[tx][i]);
+      }
+    } else if (kind >= 2) {
+      // vitpe_pack_weight_frags layout (tail2.hip): hd = k chunk; kinds 2 / 3 pack W itself in natural / acc_to_frag
+      // k order, kinds 4 / 5 pack W^T (the backward kernels' operands) the same two ways.
+      // A 32x32 tile is exactly two 1-KB fragments (output tiles p0/16, p0/16 + 1 of one k step): every thread writes 4
+      // consecutive destination elements (both dimensions are multiples of 32 for these matrices).
+      const bool tr = kind >= 4, phi = (kind & 1) != 0;
+      const int PR = tr ? ds.C : ds.R;                       // rows of the packed matrix
+      const int p0 = tr ? c0 : r0, k0 = tr ? r0 : c0;        // its row / column origin of this tile
+      const int kch = hd, KSC = kch / 32, NTr = PR / 16;
+      const int kc = k0 / kch, ks = (k0 % kch) / 32;
+      const int dd = threadIdx.x * 4, frag = dd >> 9, within = dd & 511, l = within >> 3, e0 = within & 7;
+      const int nt = p0 / 16 + frag, cc = l & 15, g = l >> 4;
+      if (16 * nt < PR) {
+        float v[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int e = e0 + j;
-        const int k = phi ? (e < 4 ? 4 * g + e : 16 + 4 * g + e - 4) : 8 * g + e;
-        v[j] = tr ? tile[k][16 * frag + cc] : tile[16 * frag + cc][k];
+        for (int j = 0; j < 4; ++j) {
+          const int e = e0 + j;
+          const int k = phi ? (e < 4 ? 4 * g + e : 16 + 4 * g + e - 4) : 8 * g + e;
+          v[j] = tr ? tile[k][16 * frag + cc] : tile[16 * frag + cc][k];
+        }
+        const size_t blk = ((size_t)kc * NTr + nt) * KSC + ks;
+        st4(dst + blk * 512 + within, v[0], v[1], v[2], v[3]);
       }
-      const size_t blk = ((size_t)kc * NTr + nt) * KSC + ks;
-      st4(dst + blk * 512 + within, v[0], v[1], v[2], v[3]);
-    }
-  } else {
-    // W[3D, D]: row = mat*D + h*HD + 16nt + cc ; col = 32ks + 8g + e  ->  block (h,mat,nt,ks), lane 16g+cc, e
-    const int D = ds.C, HD = ds.HD, NT = HD / 16, KS = D / 32;
-    for (int i = ty; i < 32; i += 8) {
-      const int r = r0 + i, c = c0 + tx;
-      if (r < ds.R && c < ds.C) {
-        const int mat = r / D, rr = r % D, h = rr / HD, nt = (rr % HD) / 16, cc = rr % 16;
-        const int ks = c / 32, g = (c % 32) / 8, e = c % 8;
-        const size_t blk = (((size_t)(h * 3 + mat) * NT + nt) * KS + ks);
-        dst[(blk * 64 + 16 * g + cc) * 8 + e] = from_f32<T>(tile[i][tx]);
+    } else {
+      // W[3D, D]: row = mat*D + h*HD + 16nt + cc ; col = 32ks + 8g + e  ->  block (h,mat,nt,ks), lane 16g+cc, e
+      const int D = ds.C, HD = hd, NT = HD / 16, KS = D / 32;
+      for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        if (r < ds.R && c < ds.C) {
+          const int mat = r / D, rr = r % D, h = rr / HD, nt = (rr % HD) / 16, cc = rr % 16;
+          const int ks = c / 32, g = (c % 32) / 8, e = c % 8;
+          const size_t blk = (((size_t)(h * 3 + mat) * NT + nt) * KS + ks);
+          dst[(blk * 64 + 16 * g + cc) * 8 + e] = from_f32<T>(tile[i][tx]);
+        }
       }
     }
-  }
+  };
+  emit(ds.kind, dst_base + ds.dst_off, ds.HD);
+  if (ds.kind2 >= 0) emit(ds.kind2, dst_base + ds.dst_off2, ds.HD2);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -980,14 +991,14 @@ extern "C" int vitpe_transpose_cast(int dtype, const float* src, void* dst, int 
 }
 
 extern "C" int vitpe_refresh_shadows(int dtype, const float* flat, void* dst_base, const void* desc, int ndesc,
-                                     int total_tiles, hipStream_t st) {
+                                     int total_tiles, const unsigned short* tile_map, hipStream_t st) {
   VITPE_REQUIRE(flat && dst_base && desc && ndesc > 0 && total_tiles > 0 && (dtype == 0 || dtype == 1));
   if (dtype == 1)
     hipLaunchKernelGGL(refresh_shadows_kernel<bf16>, dim3(total_tiles), dim3(256), 0, st, flat, (bf16*)dst_base,
-                       (const ShadowDesc*)desc, ndesc);
+                       (const ShadowDesc*)desc, ndesc, tile_map);
   else
     hipLaunchKernelGGL(refresh_shadows_kernel<float>, dim3(total_tiles), dim3(256), 0, st, flat, (float*)dst_base,
-                       (const ShadowDesc*)desc, ndesc);
+                       (const ShadowDesc*)desc, ndesc, tile_map);
   VITPE_CHECK_LAUNCH();
 }
 

@@ -125,37 +125,42 @@ class TrainEngine:
         self._fr: Dict[int, torch.Tensor] = {}
         self._frt: Dict[int, torch.Tensor] = {}
         self._gemm_weights: List[nn.Parameter] = []
+        # one record per weight matrix, up to two shadows each (the source tile is loaded once for both)
         recs, off, tile0 = [], 0, 0
-        def add(w, kind):
-            nonlocal off, tile0
-            R, C = w.shape
-            recs.append((self._off[id(w)], off, R, C, tile0, kind, self.D // self.H, 0))
+        def alloc(w):
+            nonlocal off
             o = off
-            off += (R * C + ALIGN - 1) // ALIGN * ALIGN
+            off += (w.numel() + ALIGN - 1) // ALIGN * ALIGN
+            return o
+        def add(w, kind, hd, kind2=-1, hd2=0):
+            nonlocal tile0
+            R, C = w.shape
+            o1 = alloc(w)
+            o2 = alloc(w) if kind2 >= 0 else 0
+            recs.append((self._off[id(w)], o1, o2, R, C, tile0, kind, hd, kind2, hd2, 0))
             tile0 += ((R + 31) // 32) * ((C + 31) // 32)
-            return o
-        def add_frag(w, kind, kchunk):     # vitpe_pack_weight_frags layout (block_tail2_fwd operands)
-            o = add(w, kind)
-            recs[-1] = recs[-1][:6] + (kchunk, 0)
-            return o
+            spans.append((w, kind, o1))
+            if kind2 >= 0:
+                spans.append((w, kind2, o2))
         spans = []
+        HDh = self.D // self.H
+        gen2 = self.tail2 and self.tail2_bwd
         for blk in self.model.blocks:
-            for w in (blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight):
-                self._gemm_weights.append(w)
-                if not (self.tail2 and self.tail2_bwd) or (w is blk.attn.qkv.weight and not self.lnbwd2):
-                    spans.append((w, 0, add(w, 0)))                    # (the packed transposes below replace the others)
+            qkv, proj, fc1, fc2 = blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight
+            self._gemm_weights += [qkv, proj, fc1, fc2]
+            # kind 0 transposed shadow (first-generation data-gradient GEMMs), 1 qkv pack (attention), 2 / 3 fragment packs
+            # (block_tail2_fwd), 4 / 5 fragment packs of the transposes (block_tail2_bwd, linear_lnbwd2)
             if self.attn_fused:
-                spans.append((blk.attn.qkv.weight, 1, add(blk.attn.qkv.weight, 1)))
+                add(qkv, 1, HDh, *((4, 192) if self.lnbwd2 else (0, 0)))
+            else:
+                add(qkv, 0, 0)
             if self.tail2:
-                spans.append((blk.attn.proj.weight, 2, add_frag(blk.attn.proj.weight, 2, 192)))
-                spans.append((blk.mlp.fc1.weight, 3, add_frag(blk.mlp.fc1.weight, 3, 192)))
-                spans.append((blk.mlp.fc2.weight, 3, add_frag(blk.mlp.fc2.weight, 3, 32)))
-                if self.tail2_bwd:   # the backward kernels' operands: packed TRANSPOSES (kinds 4 / 5)
-                    spans.append((blk.mlp.fc2.weight, 4, add_frag(blk.mlp.fc2.weight, 4, 192)))
-                    spans.append((blk.mlp.fc1.weight, 5, add_frag(blk.mlp.fc1.weight, 5, 32)))
-                    spans.append((blk.attn.proj.weight, 5, add_frag(blk.attn.proj.weight, 5, 192)))
-                    if self.lnbwd2:
-                        spans.append((blk.attn.qkv.weight, 4, add_frag(blk.attn.qkv.weight, 4, 192)))
+                add(proj, 2, 192, *((5, 192) if gen2 else (0, 0)))
+                add(fc1, 3, 192, *((5, 32) if gen2 else (0, 0)))
+                add(fc2, 3, 32, *((4, 192) if gen2 else (0, 0)))
+            else:
+                for w in (proj, fc1, fc2):
+                    add(w, 0, 0)
         self._shadow_flat = torch.empty(off, dtype=self.T, device=self.dev)
         for w, kind, o in spans:
             R, C = w.shape
@@ -168,12 +173,17 @@ class TrainEngine:
             else:
                 self._frt[id(w)] = self._shadow_flat[o:o + R * C].view(C, R)
         import numpy as np
-        rec = np.zeros(len(recs), dtype=np.dtype([("src", "<i8"), ("dst", "<i8"), ("R", "<i4"), ("C", "<i4"),
-                                                   ("tile0", "<i4"), ("kind", "<i4"), ("HD", "<i4"), ("pad", "<i4")]))
+        rec = np.zeros(len(recs), dtype=np.dtype([("src", "<i8"), ("dst", "<i8"), ("dst2", "<i8"), ("R", "<i4"), ("C", "<i4"),
+                                                   ("tile0", "<i4"), ("kind", "<i4"), ("HD", "<i4"), ("kind2", "<i4"),
+                                                   ("HD2", "<i4"), ("pad", "<i4")]))
         for i, r in enumerate(recs):
             rec[i] = r
         self._desc = torch.from_numpy(rec.view(np.uint8).copy()).to(self.dev)
         self._ndesc, self._ntiles = len(recs), tile0
+        tmap = np.zeros(tile0, dtype=np.int16)
+        for i, r in enumerate(recs):
+            tmap[r[5]:] = i
+        self._tile_map = torch.from_numpy(tmap).to(self.dev)
         self.refresh_shadows()
 
     def Pm(self, prm):  # fp32 master view
@@ -204,7 +214,7 @@ class TrainEngine:
     def refresh_shadows(self, cast_flat=True):
         if self.T == torch.bfloat16 and cast_flat:
             K.cast(self.flat_p, torch.bfloat16, out=self.flat_s)
-        K.refresh_shadows(self.flat_p, self._shadow_flat, self._desc, self._ndesc, self._ntiles)
+        K.refresh_shadows(self.flat_p, self._shadow_flat, self._desc, self._ndesc, self._ntiles, self._tile_map)
 
     def set_lr(self, lr: float):
         self.hp[0] = lr

@@ -732,10 +732,11 @@ def transpose_cast(src, dtype, out=None):
     return o
 
 
-def refresh_shadows(flat, dst_base, desc, ndesc, total_tiles):
-    require_device(flat, dst_base, desc)
+def refresh_shadows(flat, dst_base, desc, ndesc, total_tiles, tile_map=None):
+    require_device(flat, dst_base, desc, tile_map)
+    assert tile_map is None or (tile_map.dtype == torch.int16 and tile_map.numel() == total_tiles)
     check(lib().vitpe_refresh_shadows(dtype_code(dst_base.dtype), ptr(flat), ptr(dst_base), ptr(desc), ndesc, total_tiles,
-                                      stream_ptr()), "vitpe_refresh_shadows")
+                                      ptr(tile_map), stream_ptr()), "vitpe_refresh_shadows")
 
 
 def selftest_mma(a, bt, brow):
