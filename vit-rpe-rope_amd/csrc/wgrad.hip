@@ -371,6 +371,11 @@ static int wgrad_group_launch(int dtype, const void* problems, int nprob, unsign
   static const bool table_ok = getenv("VITPE_WGRAD_STREAMK") == nullptr;
   // (many row ranges = many partial-block flushes: with R = 42 for a single layer the atomics cost more than
   // the shared reads save -- measured 91 vs 68 us -- so small problem lists stay on the stream-K path)
+  static const int r_force = getenv("VITPE_WGRAD_RANGES") ? atoi(getenv("VITPE_WGRAD_RANGES")) : 0;
+  if (r_force > 0) R = r_force;
+  // (the whole-model list -- 73 blocks -- does not fit the table with 7 row ranges and falls through to stream-K; forcing
+  //  6 ranges so that it fits: 298 us against stream-K's 293.5, 5 ranges 319, 4 ranges 374 -- co-location cuts the HBM reads
+  //  by a third but the kernel is bound by CU-side delivery, not by HBM: tools/ab_wgrad.sh)
   if (table_ok && R >= 2 && R <= 8 && R <= min_stages / 4 && max_blocks <= 63 && np <= 31) {
     // groups = (problem, row range); greedy: next group to the XCD with the fewest workgroups so far
     int len[8] = {0, 0, 0, 0, 0, 0, 0, 0};
