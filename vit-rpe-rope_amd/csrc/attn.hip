@@ -586,7 +586,8 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, 3) void attn_bwd_reg_kernel(At
   __syncthreads();
 
   const T* const xrow = xs + c * C::LDX + 8 * g;
-  const size_t hoff = mixed ? (size_t)h * P * (HD / 2) : 0;
+  const unsigned hoff = mixed ? (unsigned)(h * P * (HD / 2)) : 0u;   // (32-bit offsets from a uniform base: the 64-bit per-lane
+                                                                      //  addresses were what the mixed build spilled)
   // cos / sin of token `tok`, features f .. f+3 (identity outside the patch tokens)
   auto cs_vec = [&](int tok, int f, f32x4& cv, f32x4& sv) {
     if (!mixed) {
@@ -594,7 +595,7 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, 3) void attn_bwd_reg_kernel(At
       sv = *reinterpret_cast<const f32x4*>(&s_sin[tok * CSLD + f]);
     } else {
       const bool ok = tok >= 1 && tok < N;
-      const size_t o = hoff + (size_t)(min(max(tok, 1), N - 1) - 1) * (HD / 2) + f;
+      const unsigned o = hoff + (unsigned)((min(max(tok, 1), N - 1) - 1) * (HD / 2) + f);
       const f32x4 cg = *reinterpret_cast<const f32x4*>(a.cos + o), sg = *reinterpret_cast<const f32x4*>(a.sin + o);
       cv = ok ? cg : (f32x4){1.f, 1.f, 1.f, 1.f};
       sv = ok ? sg : z4;
