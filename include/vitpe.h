@@ -342,17 +342,20 @@ int vitpe_head_loss(int dtype, const void* x, const float* gamma, const float* b
 /* The train step's head: vitpe_head_fwd + vitpe_cross_entropy_ctl + vitpe_head_bwd in one launch pair (classes <= 64,
  * D <= 768, else hipErrorNotSupported).  ctl as vitpe_cross_entropy_ctl.  dx: ONLY the class rows are written -- the
  * caller keeps rows 1.. of every image zero (they never change).  per_image: [B,2] work buffer ((loss, correct) per
- * image, summed in fixed order: no atomics on the totals).  Parameter gradients are accumulated.                  */
+ * image, summed in fixed order: no atomics on the totals).  Parameter gradients are accumulated.  hp_tick (nullable): the
+ * optimizer's hp block -- the launch also advances its step counter and bias corrections ([5..7]), which lets the following
+ * vitpe_adamw_step skip its own one-thread launch (zero_grad bit 1).                                              */
 int vitpe_head_step(int dtype, const void* x, const float* gamma, const float* beta, const float* Wh,
                     const float* bh, const long long* labels, float* logits, float* dlogits, float* ws_xhat,
                     float* ws_yn, float* ws_dyn, void* dx, float* out2, float* metric_acc, float* per_image,
                     const float* ctl, float* dWh, float* dbh, float* dgamma, float* dbeta, int B, int Ntok,
-                    int D, int Cn, float eps, vitpe_stream_t stream);
+                    int D, int Cn, float eps, float* hp_tick, vitpe_stream_t stream);
 
 /* ---- optimizer + weight shadows (train.py:116,195) ------------------------------------------
  * hp (device, 16 floats): [0]=lr [1]=beta1 [2]=beta2 [3]=eps [4]=weight_decay [5]=step
  * [6]=bias_correction1 [7]=bias_correction2 [8]=grad_scale.  The step counter lives on the
- * device so the call can be replayed from a hipGraph.                                        */
+ * device so the call can be replayed from a hipGraph.  zero_grad: bit 0 = clear g after the update,
+ * bit 1 = the step counter / bias corrections were already advanced (vitpe_head_step hp_tick).   */
 int vitpe_adamw_step(float* p, float* g, float* m, float* v, void* shadow_bf16, float* hp,
                      long long n, int zero_grad, vitpe_stream_t stream);
 int vitpe_cast(int dtype, const float* src, void* dst, long long n, vitpe_stream_t stream);

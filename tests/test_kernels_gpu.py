@@ -1020,8 +1020,20 @@ def test_head_step_equals_the_three_kernels(K, dt, B, N, D, Cn, nvalid):
     ws2, dyn2 = (z(B, D), z(B, D), z(B)), z(B, D)
     o2, macc, scratch = z(2), z(2), z(2 * B)
     gw2, gb2, gg2, gbt2 = z(Cn, D), z(Cn), z(D), z(D)
+    hp = torch.zeros(16, device="cuda")
+    hp[:5] = torch.tensor([1e-3, 0.9, 0.999, 1e-8, 0.05])
     for rep in range(2):
-        K.head_step(x, g, b, wh, bh, labels, lg2, dlog2, ws2, dyn2, dx2, o2, macc, scratch, ctl, gw2, gb2, gg2, gbt2)
+        K.head_step(x, g, b, wh, bh, labels, lg2, dlog2, ws2, dyn2, dx2, o2, macc, scratch, ctl, gw2, gb2, gg2, gbt2,
+                    hp_tick=(hp if rep == 1 else None))
+    # hp_tick: the launch advanced the optimizer's step counter and bias corrections exactly once (second call only)
+    assert float(hp[5]) == 1.0 and abs(float(hp[6]) - 0.1) < 1e-6 and abs(float(hp[7]) - 1e-3) < 1e-7
+    p_, g_, m_, v_ = z(64) + 1.0, z(64) + 0.5, z(64), z(64)
+    K.adamw_step(p_, g_, m_, v_, hp, zero_grad=True, ticked=True)        # uses the corrections above, does not tick again
+    assert float(hp[5]) == 1.0 and float(g_.abs().max()) == 0.0
+    pr, gr, mr, vr, hpr = z(64) + 1.0, z(64) + 0.5, z(64), z(64), hp.clone()
+    hpr[5:8] = 0.0
+    K.adamw_step(pr, gr, mr, vr, hpr)                                     # the stand-alone form ticks itself
+    assert float(hpr[5]) == 1.0 and torch.equal(p_.cpu(), pr.cpu()) and torch.equal(m_.cpu(), mr.cpu())
     assert rel_err(lg2.cpu(), lg.cpu()) < 1e-5 and rel_err(dlog2.cpu(), dlog.cpu()) < 1e-5
     assert float(dlog2[nvalid:].abs().max()) == 0.0 if nvalid < B else True
     assert rel_err(dx2[:, 0].float().cpu(), dx[:, 0].float().cpu()) < (1e-5 if dt == "f32" else 1e-2)

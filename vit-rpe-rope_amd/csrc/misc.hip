@@ -546,7 +546,15 @@ __global__ __launch_bounds__(256) void head_bwd_rows_kernel(const float* __restr
 __global__ void head_bwd_params_kernel(const float* __restrict__ dlogits, const float* __restrict__ ws_yn,
                                        const float* __restrict__ ws_dyn, const float* __restrict__ ws_xhat,
                                        float* dWh, float* dbh, float* dgamma, float* dbeta, int B, int D, int Cn,
-                                       int bchunk, const float* __restrict__ per_image, float* out2, float* metric_acc) {
+                                       int bchunk, const float* __restrict__ per_image, float* out2, float* metric_acc,
+                                       float* hp_tick) {
+  if (hp_tick != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    // the optimizer's step counter and bias corrections (adamw_tick_kernel's work: one launch less per step)
+    const float step = hp_tick[5] + 1.0f;
+    hp_tick[5] = step;
+    hp_tick[6] = 1.0f - powf(hp_tick[1], step);
+    hp_tick[7] = 1.0f - powf(hp_tick[2], step);
+  }
   if (per_image != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {
     __shared__ float sl[256], sc[256];
     float l = 0.f, cr = 0.f;
@@ -888,7 +896,8 @@ extern "C" int vitpe_head_bwd(int dtype, const float* dlogits, const float* Wh, 
   int e = (int)hipGetLastError();
   if (e) return e;
   hipLaunchKernelGGL(head_bwd_params_kernel, dim3((Cn * D + Cn + D + 255) / 256, (B + 31) / 32), dim3(256), 0, st,
-                     dlogits, ws_yn, ws_dyn, ws_xhat, dWh, dbh, dgamma, dbeta, B, D, Cn, 32, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+                     dlogits, ws_yn, ws_dyn, ws_xhat, dWh, dbh, dgamma, dbeta, B, D, Cn, 32, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
+                     (float*)nullptr);
   VITPE_CHECK_LAUNCH();
 }
 extern "C" int vitpe_head_loss(int dtype, const void* x, const float* gamma, const float* beta, const float* Wh,
@@ -912,7 +921,8 @@ extern "C" int vitpe_head_loss(int dtype, const void* x, const float* gamma, con
   int e = (int)hipGetLastError();
   if (e) return e;
   hipLaunchKernelGGL(head_bwd_params_kernel, dim3((Cn * D + Cn + D + 255) / 256, (B + 31) / 32), dim3(256), 0, st,
-                     dlogits, ws_yn, ws_dyn, ws_xhat, dWh, dbh, dgamma, dbeta, B, D, Cn, 32, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+                     dlogits, ws_yn, ws_dyn, ws_xhat, dWh, dbh, dgamma, dbeta, B, D, Cn, 32, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
+                     (float*)nullptr);
   VITPE_CHECK_LAUNCH();
 }
 template <typename T>
@@ -937,7 +947,7 @@ extern "C" int vitpe_head_step(int dtype, const void* x, const float* gamma, con
                                const float* bh, const long long* labels, float* logits, float* dlogits, float* ws_xhat,
                                float* ws_yn, float* ws_dyn, void* dx, float* out2, float* metric_acc, float* per_image,
                                const float* ctl, float* dWh, float* dbh, float* dgamma, float* dbeta, int B, int Ntok,
-                               int D, int Cn, float eps, hipStream_t st) {
+                               int D, int Cn, float eps, float* hp_tick, hipStream_t st) {
   VITPE_REQUIRE(x && gamma && beta && Wh && bh && labels && logits && dlogits && ws_xhat && ws_yn && ws_dyn && dx && out2 &&
                 per_image && ctl && dWh && dbh && dgamma && dbeta && B >= 0 && (dtype == 0 || dtype == 1));
   if (Cn < 1 || Cn > 64 || D > 768) return (int)hipErrorNotSupported;
@@ -949,7 +959,7 @@ extern "C" int vitpe_head_step(int dtype, const void* x, const float* gamma, con
   if (e) return e;
   hipLaunchKernelGGL(head_bwd_params_kernel, dim3((Cn * D + Cn + D + 255) / 256, (B + 31) / 32), dim3(256), 0, st,
                      dlogits, ws_yn, ws_dyn, ws_xhat, dWh, dbh, dgamma, dbeta, B, D, Cn, 32, (const float*)per_image, out2,
-                     metric_acc);
+                     metric_acc, hp_tick);
   VITPE_CHECK_LAUNCH();
 }
 extern "C" int vitpe_embed_bwd(int dtype, const void* dtok, float* dcls, float* dape, void* dpatch, int B, int Ntok,
@@ -967,10 +977,10 @@ extern "C" int vitpe_embed_bwd(int dtype, const void* dtok, float* dcls, float* 
 extern "C" int vitpe_adamw_step(float* p, float* g, float* m, float* v, void* shadow_bf16, float* hp, long long n,
                                 int zero_grad, hipStream_t st) {
   VITPE_REQUIRE(p && g && m && v && hp && n >= 0);
-  hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, st, hp);
+  if (!(zero_grad & 2)) hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, st, hp);   // bit 1: the caller ticked already
   if (n > 0) {
     const unsigned blocks = (unsigned)min((n + 255) / 256, (long long)4096);
-    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, (bf16*)shadow_bf16, hp, n, zero_grad);
+    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, (bf16*)shadow_bf16, hp, n, zero_grad & 1);
   }
   VITPE_CHECK_LAUNCH();
 }

@@ -402,13 +402,15 @@ class TrainEngine:
     def _fwd_train(self):
         self._forward(head=not self.fuse_head)
 
-    def _loss(self):
+    def _loss(self, tick=True):
+        """tick: this loss belongs to a full step -- the fused head launch also advances the optimizer's step counter."""
+        self._ticked = bool(tick and self.fuse_head)
         if self.fuse_head:   # final LayerNorm + head + CE + accuracy + dlogits + the head's backward: one launch pair
             mdl, G = self.model, self.Gr
             K.head_step(self.x[-1], mdl.norm.weight.data, mdl.norm.bias.data, mdl.head.weight.data, mdl.head.bias.data,
                         self.labels, self.logits, self.dlogits, self.head_ws, self.ws_dyn, self.dx_out[self.Lyr], self.out2,
                         self.metric_acc, self.head_scratch, self.ce_ctl, G(mdl.head.weight), G(mdl.head.bias),
-                        G(mdl.norm.weight), G(mdl.norm.bias), eps=mdl.norm.eps)
+                        G(mdl.norm.weight), G(mdl.norm.bias), eps=mdl.norm.eps, hp_tick=(self.hp if tick else None))
             return
         K.cross_entropy_ctl(self.logits, self.labels, self.ce_ctl, dlogits=self.dlogits, out2=self.out2,
                             metric_acc=self.metric_acc)
@@ -546,8 +548,9 @@ class TrainEngine:
             main.wait_stream(self.side)   # join: every gradient is complete before the all-reduce / optimizer
 
     def _optimizer(self):
-        K.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.hp, shadow_bf16=self.flat_s,
+        K.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.hp, shadow_bf16=self.flat_s, ticked=getattr(self, "_ticked", False),
                      zero_grad=True)
+        self._ticked = False
         self.refresh_shadows(cast_flat=False)
 
     def _allreduce(self):
@@ -723,7 +726,7 @@ class TrainEngine:
 
     def forward_backward(self):
         """forward + loss + backward on the resident batch without the optimizer (tests / parity)."""
-        self._fwd_train(); self._loss(); self._backward()
+        self._fwd_train(); self._loss(tick=False); self._backward()
 
     def forward_only(self, images: torch.Tensor) -> torch.Tensor:
         """Logits [n, classes] of `images` [n <= B, C, S, S] (eager forward on the same kernels)."""

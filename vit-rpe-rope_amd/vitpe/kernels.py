@@ -692,25 +692,27 @@ def head_loss(x, gamma, beta, wh, bh, labels, logits, dlogits, ws, ws_dyn, dx, o
 
 
 def head_step(x, gamma, beta, wh, bh, labels, logits, dlogits, ws, ws_dyn, dx, out2, metric_acc, per_image, ctl, dwh, dbh,
-              dgamma, dbeta, eps=1e-5):
+              dgamma, dbeta, eps=1e-5, hp_tick=None):
     """The train step's head in one launch pair: final LayerNorm of the class row + logits + cross-entropy (device-side
     scalars `ctl`, as cross_entropy_ctl) + dlogits + the class row of dx (rows 1.. of dx are NOT touched: the caller
     keeps them zero) + parameter gradients (accumulated).  ws = (xhat, yn, rstd) work buffers; per_image [B,2] fp32."""
     require_device(x, gamma, beta, wh, bh, labels, logits, dlogits, ws[0], ws[1], ws_dyn, dx, out2, metric_acc, per_image, ctl,
-                   dwh, dbh, dgamma, dbeta)
+                   dwh, dbh, dgamma, dbeta, hp_tick)
     B, Ntok, D = x.shape
     Cn = wh.shape[0]
     assert labels.dtype == torch.int64 and per_image.numel() >= 2 * B and ctl.numel() >= 3
     check(lib().vitpe_head_step(dtype_code(x.dtype), ptr(x), ptr(gamma), ptr(beta), ptr(wh), ptr(bh), ptr(labels), ptr(logits),
                                 ptr(dlogits), ptr(ws[0]), ptr(ws[1]), ptr(ws_dyn), ptr(dx), ptr(out2), ptr(metric_acc),
                                 ptr(per_image), ptr(ctl), ptr(dwh), ptr(dbh), ptr(dgamma), ptr(dbeta), B, Ntok, D, Cn, float(eps),
-                                stream_ptr()), "vitpe_head_step")
+                                ptr(hp_tick), stream_ptr()), "vitpe_head_step")
 
 
 # ---- optimizer / shadows --------------------------------------------------------------------
-def adamw_step(p, g, m, v, hp, shadow_bf16=None, zero_grad=True):
+def adamw_step(p, g, m, v, hp, shadow_bf16=None, zero_grad=True, ticked=False):
+    """ticked: the step counter / bias corrections in hp were already advanced (head_step hp_tick)."""
     require_device(p, g, m, v, hp, shadow_bf16)
-    check(lib().vitpe_adamw_step(ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow_bf16), ptr(hp), p.numel(), int(zero_grad),
+    check(lib().vitpe_adamw_step(ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow_bf16), ptr(hp), p.numel(),
+                                 int(bool(zero_grad)) | (2 if ticked else 0),
                                  stream_ptr()), "vitpe_adamw_step")
 
 
