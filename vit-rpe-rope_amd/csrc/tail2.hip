@@ -30,6 +30,7 @@
 // values of a token plus two v_permlane swaps.  Rows past M in the last tile are computed as copies of row M - 1 (clamped
 // row index for loads AND stores: identical values written to the same address), so there is no guarded path.
 #include "common.h"
+#include <type_traits>
 
 #ifndef T2_NT_HID
 #define T2_NT_HID true
@@ -70,6 +71,7 @@ struct Tail2Args {
 
 constexpr int T2_D = 192, T2_NT = 12, T2_KS = 6, T2_WAVES = 9;   // compute waves per workgroup
 constexpr int T2_THREADS = 64 * (T2_WAVES + 2);                      // + two loader waves
+constexpr int T2F_THREADS = 64 * (T2_WAVES + 3);                     // forward: + the helper wave of a split ninth tile
 constexpr int T2_MAXHID = 1536, T2_NFLAG = T2_MAXHID / 64 + 2;
 constexpr int T2_CH = 64, T2_CNT = T2_CH / 16, T2_CKS = T2_CH / 32;   // hidden chunk per slab: output tiles of fc1, k steps of fc2
 constexpr int T2_HALF = T2_CNT * T2_KS;                               // 24 fragments of fc1, 24 of fc2 (12 x 2) per slab
@@ -241,12 +243,12 @@ VITPE_DEV void t2_substep(const bf16* w1f, const bf16* w2f, const Frag<bf16> (&b
 }
 
 template <bool SAVE, bool CENSUS, int EXP = 0>
-__global__ __launch_bounds__(T2_THREADS) void block_tail2_fwd_kernel(Tail2Args a) {
+__global__ __launch_bounds__(T2F_THREADS) void block_tail2_fwd_kernel(Tail2Args a) {
   using T = bf16;
   constexpr int D = T2_D, NT = T2_NT, KS = T2_KS;
   __shared__ __attribute__((aligned(16))) T sW[3 * T2_SLABF * 512];
   __shared__ __attribute__((aligned(16))) float sPar[4 * T2_D + T2_MAXHID];   // bp | gamma | beta | b2 | b1
-  __shared__ int sReady[T2_NFLAG], sDone[T2_NFLAG];   // loader <-> compute handshakes (see below)
+  __shared__ int sReady[T2_NFLAG], sDone[T2_NFLAG], sComb;   // loader <-> compute handshakes (see below)
 
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -254,8 +256,17 @@ __global__ __launch_bounds__(T2_THREADS) void block_tail2_fwd_kernel(Tail2Args a
   // tiles of this workgroup / wave
   const int ntiles = (a.M + 15) / 16, base = ntiles / (int)gridDim.x, rem = ntiles % (int)gridDim.x;
   const int tile0 = (int)blockIdx.x * base + min((int)blockIdx.x, rem), ntile_wg = base + ((int)blockIdx.x < rem ? 1 : 0);
-  const bool active = wave < ntile_wg;                        // wave-uniform
-  const int rowc = min(16 * (tile0 + wave) + c, a.M - 1);    // rows past M: copies of row M - 1
+  // A workgroup with NINE tiles would put three compute waves on SIMD 0 and finish 26 % after the eight-tile ones (the
+  // kernel's duration).  Its ninth tile is therefore SPLIT between wave 8 (SIMD 0) and wave 11 (SIMD 3, which hosts only
+  // two compute waves and no loader): both run the proj + LayerNorm2 prologue for the tile, wave 8 then takes the even
+  // 64-wide hidden chunks and wave 11 the odd ones (fc1 + GELU of chunk p while slab p is resident, fc2 of chunk p under
+  // slab p + 1), and wave 11's partial fc2 sums reach wave 8 through a slab buffer that has gone idle.
+  const bool split = ntile_wg == T2_WAVES;
+  const int half = !split ? -1 : wave == T2_WAVES - 1 ? 0 : wave == T2_WAVES + 2 ? 1 : -1;   // -1: a whole tile
+  const bool active = wave < ntile_wg || half == 1;           // wave-uniform
+  const int nsig = ntile_wg + (split ? 1 : 0);                // compute waves that count themselves into sDone[]
+  const int mytile = tile0 + (half == 1 ? T2_WAVES - 1 : wave);
+  const int rowc = min(16 * mytile + c, a.M - 1);            // rows past M: copies of row M - 1
 
   unsigned long long acc_sync = 0, acc_fc1 = 0, acc_mix = 0, tm0 = 0;
   auto now = [&]() -> unsigned long long { return CENSUS ? __builtin_amdgcn_s_memtime() : 0ull; };
@@ -269,12 +280,13 @@ __global__ __launch_bounds__(T2_THREADS) void block_tail2_fwd_kernel(Tail2Args a
   };
   // Wp -> fragments [0, 72): every wave issues its share (the first product waits for these)
 #pragma unroll
-  for (int i = 0; i < (NT * KS + T2_THREADS / 64 - 1) / (T2_THREADS / 64); ++i) {
-    const int f = wave + (T2_THREADS / 64) * i;
+  for (int i = 0; i < (NT * KS + T2F_THREADS / 64 - 1) / (T2F_THREADS / 64); ++i) {
+    const int f = wave + (T2F_THREADS / 64) * i;
     if (f < NT * KS) dma1(reinterpret_cast<const T*>(a.wp) + (size_t)f * 512, f);
   }
   if (threadIdx.x < T2_NFLAG) { sReady[threadIdx.x] = 0; sDone[threadIdx.x] = 0; }
-  for (int i = threadIdx.x; i < 4 * D + HID; i += T2_THREADS) {     // parameters -> LDS
+  if (threadIdx.x == 0) sComb = 0;
+  for (int i = threadIdx.x; i < 4 * D + HID; i += T2F_THREADS) {     // parameters -> LDS
     const int k = i / D;
     sPar[i] = k == 0 ? a.bp[i] : k == 1 ? a.gamma[i - D] : k == 2 ? a.beta[i - 2 * D] : k == 3 ? a.b2[i - 3 * D] : a.b1[i - 4 * D];
   }
@@ -289,7 +301,7 @@ __global__ __launch_bounds__(T2_THREADS) void block_tail2_fwd_kernel(Tail2Args a
   // slab (sDone[0]: the proj fragments, sDone[s + 1]: slab s), and a loader refills a buffer when all active waves have
   // left it.  The compute waves never wait for each other, so the waves of a SIMD drift apart and one's MFMAs run under
   // another's GELU.
-  if (wave >= T2_WAVES) {
+  if (wave == T2_WAVES || wave == T2_WAVES + 1) {
     const bool is1 = wave == T2_WAVES;                 // fc1 halves : fc2 halves
     const int first = is1 ? 0 : 1, last = is1 ? nchunk - 1 : nchunk;
     const T* const src = is1 ? reinterpret_cast<const T*>(a.w1) : reinterpret_cast<const T*>(a.w2) - (size_t)T2_HALF * 512;
@@ -300,7 +312,7 @@ __global__ __launch_bounds__(T2_THREADS) void block_tail2_fwd_kernel(Tail2Args a
       for (int f = 0; f < T2_HALF; ++f) dma1(src + ((size_t)sl * T2_HALF + f) * 512, b0 + f);
     };
     auto wait_done = [&](int k) {     // all active compute waves have counted themselves into sDone[k]
-      while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sDone[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < ntile_wg) __builtin_amdgcn_s_sleep(2);
+      while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sDone[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < nsig) __builtin_amdgcn_s_sleep(2);
       asm volatile("" ::: "memory");
     };
     auto raise = [&](int sl) {
@@ -339,151 +351,206 @@ __global__ __launch_bounds__(T2_THREADS) void block_tail2_fwd_kernel(Tail2Args a
     if (lane == 0) atomicAdd(&sDone[k], 1);
   };
 
-  // ---- compute waves: this wave's tokens as B fragments (natural k order), straight from global ---------------------------
-  Frag<T> bf[KS];
-  if (active) {
-    const T* ar = reinterpret_cast<const T*>(a.a) + (size_t)rowc * D + 8 * g;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) bf[ks] = ld_frag(ar + 32 * ks);
-  }
-  __builtin_amdgcn_s_waitcnt(0x0070);           // vmcnt(0) lgkmcnt(0): Wp pieces, token fragments, LDS parameter stores
-  asm volatile("s_barrier" ::: "memory");       // the one barrier
-  if (!active) return;
-  stamp(1);
-  // the residual rows: issued now (no LDS-DMA of this wave is in flight any more, so the compiler's own vmcnt waits are
-  // counted ones again) and landing under the first product
-  bf16x4 xres[NT];
-  {
-    const T* xr = reinterpret_cast<const T*>(a.xin) + (size_t)rowc * D + 4 * g;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) xres[nt] = *reinterpret_cast<const bf16x4*>(xr + 16 * nt);
-  }
-
-  // ---- x_mid = x_in + proj + bias; LayerNorm2 statistics; xn -> B fragments of fc1 --------------------------------------
-  T* const xmr = reinterpret_cast<T*>(a.xmid) + (size_t)rowc * D;
-  const float invD = 1.0f / (float)D;
-  {
-    f32x4 acc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = *reinterpret_cast<const f32x4*>(sPar + 16 * nt + 4 * g);
-    t2_gemm<NT, KS, 12>(sW + lane * 8, bf, acc);
-    signal_done(0);
-    stamp(2);
-    float s1 = 0.f;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { acc[nt][r] = to_f32(from_f32<T>(acc[nt][r] + (float)xres[nt][r])); s1 += acc[nt][r]; }   // values as stored
+  // The rest of the kernel exists twice -- whole-tile waves and the two half-tile waves of a nine-tile workgroup -- and is
+  // entered through ONE wave-uniform branch right here: with the branch around the main loop only, the two paths' register
+  // assignments met in the middle of the kernel and the compiler spilled 58 registers around it for every wave.
+  auto body = [&](auto hm) {
+    constexpr bool HALFW = decltype(hm)::value;
+    // ---- compute waves: this wave's tokens as B fragments (natural k order), straight from global ---------------------------
+    Frag<T> bf[KS];
+    if (active) {
+      const T* ar = reinterpret_cast<const T*>(a.a) + (size_t)rowc * D + 8 * g;
+  #pragma unroll
+      for (int ks = 0; ks < KS; ++ks) bf[ks] = ld_frag(ar + 32 * ks);
     }
-#pragma unroll
-    for (int nt = 0; nt < NT; nt += 2) t2_store_pair<false>(xmr, nt, g, acc[nt], acc[nt + 1]);
-    const float mean = t2_xg_sum(s1) * invD;
-    float s2 = 0.f;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { const float d = acc[nt][r] - mean; s2 += d * d; }
-    const float rstd = 1.0f / sqrtf(t2_xg_sum(s2) * invD + a.eps2);
-    if (g == 0) { a.mean2[rowc] = mean; a.rstd2[rowc] = rstd; }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      __builtin_amdgcn_sched_barrier(0);
-      const f32x4 gv = *reinterpret_cast<const f32x4*>(sPar + D + 16 * nt + 4 * g);
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(sPar + 2 * D + 16 * nt + 4 * g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[nt][r] = fmaf((acc[nt][r] - mean) * rstd, gv[r], bv[r]);
-    }
-    if (a.xn_out != nullptr) {
-      T* xnr = reinterpret_cast<T*>(a.xn_out) + (size_t)rowc * D;
-#pragma unroll
-      for (int nt = 0; nt < NT; nt += 2) t2_store_pair<true>(xnr, nt, g, acc[nt], acc[nt + 1]);
-    }
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) bf[ks] = acc_to_frag<T>(acc[2 * ks], acc[2 * ks + 1]);   // phi order inside the chunk
-  }
-
-  // ---- the MLP branch: slab p = fc1 rows of the 64-wide chunk p | fc2 k chunk p - 1, two pipeline steps per slab ----------
-  f32x4 acc2[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) acc2[nt] = *reinterpret_cast<const f32x4*>(sPar + 3 * D + 16 * nt + 4 * g);   // b2
-  T* const gpr = SAVE ? reinterpret_cast<T*>(a.gp_out) + (size_t)rowc * HID : nullptr;
-  T* const hr = SAVE ? reinterpret_cast<T*>(a.h_out) + (size_t)rowc * HID : nullptr;
-  f32x4 aX[2], aY[2];          // fc1 accumulators of the even / odd 32-wide sub-chunk in flight
-  Frag<T> hP, hQ;              // gelu fragments of the even / odd sub-chunk in flight
-  const float* const b1l = sPar + 4 * D + 4 * g;
-  auto bias1 = [&](f32x4 (&acc1)[2], int t) {     // fc1 bias of sub-chunk t = the accumulators' initial value
-    acc1[0] = *reinterpret_cast<const f32x4*>(b1l + 32 * t);
-    acc1[1] = *reinterpret_cast<const f32x4*>(b1l + 32 * t + 16);
-  };
-
-  stamp(3);
-  wait_ready(0);
-  stamp(4);
-  {
-    const T* wb = sW + 2 * T2_SLABF * 512 + lane * 8;
-    bias1(aX, 0);
-    t2_substep<true, false, false, SAVE, EXP>(wb, wb, bf, aX, aY, hQ, hQ, acc2, gpr, hr, g);                           // F1_0
-    bias1(aY, 1);
-    t2_substep<true, true, false, SAVE, EXP>(wb + 2 * KS * 512, wb, bf, aY, aX, hQ, hP, acc2, gpr, hr, g);             // F1_1 G_0
-    signal_done(1);
-  }
-  stamp(5);
-  for (int p = 1; p < nchunk; ++p) {
-    if (CENSUS) tm0 = now();
-    wait_ready(p);
-    if (CENSUS) { const unsigned long long t = now(); acc_sync += t - tm0; tm0 = t; }
+    __builtin_amdgcn_s_waitcnt(0x0070);           // vmcnt(0) lgkmcnt(0): Wp pieces, token fragments, LDS parameter stores
+    asm volatile("s_barrier" ::: "memory");       // the one barrier
+    if (!active) return;
+    stamp(1);
+    // the residual rows: issued now (no LDS-DMA of this wave is in flight any more, so the compiler's own vmcnt waits are
+    // counted ones again) and landing under the first product
+    bf16x4 xres[NT];
     {
-      const T* wb = sW + ((p + 2) % 3) * T2_SLABF * 512 + lane * 8;
-      const T* w2b = wb + T2_HALF * 512;
-      bias1(aX, 2 * p);
-      t2_substep<true, true, true, SAVE, EXP>(wb, w2b, bf, aX, aY, hP, hQ, acc2, gpr + 32 * (2 * p - 1), hr + 32 * (2 * p - 1), g);
-      if (CENSUS) { const unsigned long long t = now(); acc_fc1 += t - tm0; tm0 = t; }
-      bias1(aY, 2 * p + 1);
-      t2_substep<true, true, true, SAVE, EXP>(wb + 2 * KS * 512, w2b + NT * 512, bf, aY, aX, hQ, hP, acc2, gpr + 32 * (2 * p),
-                                         hr + 32 * (2 * p), g);
-      signal_done(p + 1);
-      if (CENSUS) acc_mix += now() - tm0;
+      const T* xr = reinterpret_cast<const T*>(a.xin) + (size_t)rowc * D + 4 * g;
+  #pragma unroll
+      for (int nt = 0; nt < NT; ++nt) xres[nt] = *reinterpret_cast<const bf16x4*>(xr + 16 * nt);
     }
-  }
-  stamp(6);
-  wait_ready(nchunk);
-  stamp(7);
-  if (CENSUS && lane == 0) {
-    unsigned long long* cz = a.census + ((size_t)blockIdx.x * T2_WAVES + wave) * 16;
-    cz[10] = acc_sync; cz[11] = acc_fc1; cz[12] = acc_mix;
-  }
-  {
-    const T* w2b = sW + ((nchunk + 2) % 3) * T2_SLABF * 512 + T2_HALF * 512 + lane * 8;
-    const int tl = 2 * nchunk - 1;
-    t2_substep<false, true, true, SAVE, EXP>(w2b, w2b, bf, aX, aY, hP, hQ, acc2, gpr + 32 * tl, hr + 32 * tl, g);        // G_last F2
-    t2_substep<false, false, true, SAVE, EXP>(w2b, w2b + NT * 512, bf, aX, aY, hQ, hQ, acc2, gpr, hr, g);               // F2_last
-  }
-  stamp(8);
 
-  // ---- out = x_mid + fc2 + bias; statistics for the next block's LayerNorm1 ----------------------------------------------
-  {
-    T* const outr = reinterpret_cast<T*>(a.out) + (size_t)rowc * D;
-    float s1 = 0.f;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const f32x4 rv = ld4(xmr + 16 * nt + 4 * g);     // (this lane's own earlier stores: same wave, same addresses)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { acc2[nt][r] = to_f32(from_f32<T>(acc2[nt][r] + rv[r])); s1 += acc2[nt][r]; }
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; nt += 2) t2_store_pair<false>(outr, nt, g, acc2[nt], acc2[nt + 1]);
-    if (a.mean_out != nullptr) {
+    // ---- x_mid = x_in + proj + bias; LayerNorm2 statistics; xn -> B fragments of fc1 --------------------------------------
+    T* const xmr = reinterpret_cast<T*>(a.xmid) + (size_t)rowc * D;
+    const float invD = 1.0f / (float)D;
+    {
+      f32x4 acc[NT];
+  #pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = *reinterpret_cast<const f32x4*>(sPar + 16 * nt + 4 * g);
+      t2_gemm<NT, KS, 12>(sW + lane * 8, bf, acc);
+      signal_done(0);
+      stamp(2);
+      float s1 = 0.f;
+  #pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) { acc[nt][r] = to_f32(from_f32<T>(acc[nt][r] + (float)xres[nt][r])); s1 += acc[nt][r]; }   // values as stored
+      }
+  #pragma unroll
+      for (int nt = 0; nt < NT; nt += 2) t2_store_pair<false>(xmr, nt, g, acc[nt], acc[nt + 1]);
       const float mean = t2_xg_sum(s1) * invD;
       float s2 = 0.f;
-#pragma unroll
+  #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const float d = acc2[nt][r] - mean; s2 += d * d; }
-      const float var = t2_xg_sum(s2) * invD;
-      if (g == 0) { a.mean_out[rowc] = mean; a.rstd_out[rowc] = 1.0f / sqrtf(var + a.eps_next); }
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) { const float d = acc[nt][r] - mean; s2 += d * d; }
+      const float rstd = 1.0f / sqrtf(t2_xg_sum(s2) * invD + a.eps2);
+      if (g == 0) { a.mean2[rowc] = mean; a.rstd2[rowc] = rstd; }
+  #pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(sPar + D + 16 * nt + 4 * g);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(sPar + 2 * D + 16 * nt + 4 * g);
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) acc[nt][r] = fmaf((acc[nt][r] - mean) * rstd, gv[r], bv[r]);
+      }
+      if (a.xn_out != nullptr) {
+        T* xnr = reinterpret_cast<T*>(a.xn_out) + (size_t)rowc * D;
+  #pragma unroll
+        for (int nt = 0; nt < NT; nt += 2) t2_store_pair<true>(xnr, nt, g, acc[nt], acc[nt + 1]);
+      }
+  #pragma unroll
+      for (int ks = 0; ks < KS; ++ks) bf[ks] = acc_to_frag<T>(acc[2 * ks], acc[2 * ks + 1]);   // phi order inside the chunk
     }
-  }
-  stamp(9);
+
+    // ---- the MLP branch: slab p = fc1 rows of the 64-wide chunk p | fc2 k chunk p - 1, two pipeline steps per slab ----------
+    f32x4 acc2[NT];
+  #pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc2[nt] = *reinterpret_cast<const f32x4*>(sPar + 3 * D + 16 * nt + 4 * g);   // b2
+    T* const gpr = SAVE ? reinterpret_cast<T*>(a.gp_out) + (size_t)rowc * HID : nullptr;
+    T* const hr = SAVE ? reinterpret_cast<T*>(a.h_out) + (size_t)rowc * HID : nullptr;
+    f32x4 aX[2], aY[2];          // fc1 accumulators of the even / odd 32-wide sub-chunk in flight
+    Frag<T> hP, hQ;              // gelu fragments of the even / odd sub-chunk in flight
+    const float* const b1l = sPar + 4 * D + 4 * g;
+    auto bias1 = [&](f32x4 (&acc1)[2], int t) {     // fc1 bias of sub-chunk t = the accumulators' initial value
+      acc1[0] = *reinterpret_cast<const f32x4*>(b1l + 32 * t);
+      acc1[1] = *reinterpret_cast<const f32x4*>(b1l + 32 * t + 16);
+    };
+
+    if constexpr (HALFW) {
+      // ---- half of a split tile: chunk p's fc1 + GELU while slab p is resident, its fc2 under slab p + 1 (see the top) ---------
+      if (half == 1) {
+  #pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc2[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};       // the bias is wave 8's
+      }
+      for (int p = 0; p <= nchunk; ++p) {
+        wait_ready(p);
+        const T* wb = sW + ((p + 2) % 3) * T2_SLABF * 512 + lane * 8;
+        if (p < nchunk && (p & 1) == half) {
+          bias1(aX, 2 * p);
+          t2_substep<true, false, false, SAVE, EXP>(wb, wb, bf, aX, aY, hQ, hQ, acc2, gpr, hr, g);
+          bias1(aY, 2 * p + 1);
+          t2_substep<true, true, false, SAVE, EXP>(wb + 2 * KS * 512, wb, bf, aY, aX, hQ, hP, acc2, gpr + 32 * (2 * p),
+                                                   hr + 32 * (2 * p), g);
+          t2_substep<false, true, false, SAVE, EXP>(wb, wb, bf, aX, aY, hQ, hQ, acc2, gpr + 32 * (2 * p + 1), hr + 32 * (2 * p + 1), g);
+        } else if (p >= 1 && ((p - 1) & 1) == half) {
+          const T* w2b = wb + T2_HALF * 512;
+          Frag<T> hdummy;
+          t2_substep<false, false, true, SAVE, EXP>(w2b, w2b, bf, aX, aY, hP, hdummy, acc2, gpr, hr, g);
+          t2_substep<false, false, true, SAVE, EXP>(w2b, w2b + NT * 512, bf, aX, aY, hQ, hdummy, acc2, gpr, hr, g);
+        }
+        signal_done(p + 1);
+      }
+      // wave 11's partial sums -> wave 8 through the buffer slab nchunk - 2 lived in (idle once everyone has consumed it)
+      float* const comb = reinterpret_cast<float*>(sW + (nchunk % 3) * T2_SLABF * 512) + lane;
+      if (half == 1) {
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sDone[nchunk - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < nsig)
+          __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+  #pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) comb[(nt * 4 + r) * 64] = acc2[nt][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&sComb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+      }
+      while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sComb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0)
+        __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+  #pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) acc2[nt][r] += comb[(nt * 4 + r) * 64];
+    } else {
+      stamp(3);
+      wait_ready(0);
+      stamp(4);
+      {
+        const T* wb = sW + 2 * T2_SLABF * 512 + lane * 8;
+        bias1(aX, 0);
+        t2_substep<true, false, false, SAVE, EXP>(wb, wb, bf, aX, aY, hQ, hQ, acc2, gpr, hr, g);                           // F1_0
+        bias1(aY, 1);
+        t2_substep<true, true, false, SAVE, EXP>(wb + 2 * KS * 512, wb, bf, aY, aX, hQ, hP, acc2, gpr, hr, g);             // F1_1 G_0
+        signal_done(1);
+      }
+      stamp(5);
+      for (int p = 1; p < nchunk; ++p) {
+        if (CENSUS) tm0 = now();
+        wait_ready(p);
+        if (CENSUS) { const unsigned long long t = now(); acc_sync += t - tm0; tm0 = t; }
+        {
+          const T* wb = sW + ((p + 2) % 3) * T2_SLABF * 512 + lane * 8;
+          const T* w2b = wb + T2_HALF * 512;
+          bias1(aX, 2 * p);
+          t2_substep<true, true, true, SAVE, EXP>(wb, w2b, bf, aX, aY, hP, hQ, acc2, gpr + 32 * (2 * p - 1), hr + 32 * (2 * p - 1), g);
+          if (CENSUS) { const unsigned long long t = now(); acc_fc1 += t - tm0; tm0 = t; }
+          bias1(aY, 2 * p + 1);
+          t2_substep<true, true, true, SAVE, EXP>(wb + 2 * KS * 512, w2b + NT * 512, bf, aY, aX, hQ, hP, acc2, gpr + 32 * (2 * p),
+                                             hr + 32 * (2 * p), g);
+          signal_done(p + 1);
+          if (CENSUS) acc_mix += now() - tm0;
+        }
+      }
+      stamp(6);
+      wait_ready(nchunk);
+      stamp(7);
+      if (CENSUS && lane == 0) {
+        unsigned long long* cz = a.census + ((size_t)blockIdx.x * T2_WAVES + wave) * 16;
+        cz[10] = acc_sync; cz[11] = acc_fc1; cz[12] = acc_mix;
+      }
+      {
+        const T* w2b = sW + ((nchunk + 2) % 3) * T2_SLABF * 512 + T2_HALF * 512 + lane * 8;
+        const int tl = 2 * nchunk - 1;
+        t2_substep<false, true, true, SAVE, EXP>(w2b, w2b, bf, aX, aY, hP, hQ, acc2, gpr + 32 * tl, hr + 32 * tl, g);        // G_last F2
+        t2_substep<false, false, true, SAVE, EXP>(w2b, w2b + NT * 512, bf, aX, aY, hQ, hQ, acc2, gpr, hr, g);               // F2_last
+      }
+    }
+    stamp(8);
+
+    // ---- out = x_mid + fc2 + bias; statistics for the next block's LayerNorm1 ----------------------------------------------
+    {
+      T* const outr = reinterpret_cast<T*>(a.out) + (size_t)rowc * D;
+      float s1 = 0.f;
+  #pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f32x4 rv = ld4(xmr + 16 * nt + 4 * g);     // (this lane's own earlier stores: same wave, same addresses)
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) { acc2[nt][r] = to_f32(from_f32<T>(acc2[nt][r] + rv[r])); s1 += acc2[nt][r]; }
+      }
+  #pragma unroll
+      for (int nt = 0; nt < NT; nt += 2) t2_store_pair<false>(outr, nt, g, acc2[nt], acc2[nt + 1]);
+      if (a.mean_out != nullptr) {
+        const float mean = t2_xg_sum(s1) * invD;
+        float s2 = 0.f;
+  #pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) { const float d = acc2[nt][r] - mean; s2 += d * d; }
+        const float var = t2_xg_sum(s2) * invD;
+        if (g == 0) { a.mean_out[rowc] = mean; a.rstd_out[rowc] = 1.0f / sqrtf(var + a.eps_next); }
+      }
+    }
+    stamp(9);
+  };
+  if (half >= 0) body(std::true_type{});
+  else body(std::false_type{});
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -947,15 +1014,15 @@ static int tail2_launch(int dtype, const void* attn_out, const void* x_in, const
   a.census = census;
   if (census != nullptr) {
     VITPE_REQUIRE(gp_out != nullptr);
-    if (exp == 1) hipLaunchKernelGGL((block_tail2_fwd_kernel<true, true, 1>), dim3(grid), dim3(T2_THREADS), 0, stream, a);
-    else if (exp == 2) hipLaunchKernelGGL((block_tail2_fwd_kernel<true, true, 2>), dim3(grid), dim3(T2_THREADS), 0, stream, a);
-    else if (exp == 4) hipLaunchKernelGGL((block_tail2_fwd_kernel<true, true, 4>), dim3(grid), dim3(T2_THREADS), 0, stream, a);
-    else if (exp == 7) hipLaunchKernelGGL((block_tail2_fwd_kernel<true, true, 7>), dim3(grid), dim3(T2_THREADS), 0, stream, a);
-    else hipLaunchKernelGGL((block_tail2_fwd_kernel<true, true>), dim3(grid), dim3(T2_THREADS), 0, stream, a);
+    if (exp == 1) hipLaunchKernelGGL((block_tail2_fwd_kernel<true, true, 1>), dim3(grid), dim3(T2F_THREADS), 0, stream, a);
+    else if (exp == 2) hipLaunchKernelGGL((block_tail2_fwd_kernel<true, true, 2>), dim3(grid), dim3(T2F_THREADS), 0, stream, a);
+    else if (exp == 4) hipLaunchKernelGGL((block_tail2_fwd_kernel<true, true, 4>), dim3(grid), dim3(T2F_THREADS), 0, stream, a);
+    else if (exp == 7) hipLaunchKernelGGL((block_tail2_fwd_kernel<true, true, 7>), dim3(grid), dim3(T2F_THREADS), 0, stream, a);
+    else hipLaunchKernelGGL((block_tail2_fwd_kernel<true, true>), dim3(grid), dim3(T2F_THREADS), 0, stream, a);
   } else if (gp_out != nullptr) {
-    hipLaunchKernelGGL((block_tail2_fwd_kernel<true, false>), dim3(grid), dim3(T2_THREADS), 0, stream, a);
+    hipLaunchKernelGGL((block_tail2_fwd_kernel<true, false>), dim3(grid), dim3(T2F_THREADS), 0, stream, a);
   } else {
-    hipLaunchKernelGGL((block_tail2_fwd_kernel<false, false>), dim3(grid), dim3(T2_THREADS), 0, stream, a);
+    hipLaunchKernelGGL((block_tail2_fwd_kernel<false, false>), dim3(grid), dim3(T2F_THREADS), 0, stream, a);
   }
   VITPE_CHECK_LAUNCH();
 }
