@@ -2,7 +2,7 @@
 # weight-gradient placement A/B on one box: stream-K vs the XCD-co-located table with 4..7 row ranges
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
-for v in streamk 0 4 5 6; do
+for v in streamk 0 6 7; do
   if [ $v = streamk ]; then export VITPE_WGRAD_STREAMK=1; unset VITPE_WGRAD_RANGES; else unset VITPE_WGRAD_STREAMK; export VITPE_WGRAD_RANGES=$v; fi
   echo "== $v"; timeout -k 10 200 python bench.py --steps 100 --warmup 20 --no-cpu-baseline | python3 -c "
 import json,sys

@@ -375,7 +375,8 @@ static int wgrad_group_launch(int dtype, const void* problems, int nprob, unsign
   if (r_force > 0) R = r_force;
   // (the whole-model list -- 73 blocks -- does not fit the table with 7 row ranges and falls through to stream-K; forcing
   //  6 ranges so that it fits: 298 us against stream-K's 293.5, 5 ranges 319, 4 ranges 374 -- co-location cuts the HBM reads
-  //  by a third but the kernel is bound by CU-side delivery, not by HBM: tools/ab_wgrad.sh)
+  //  by a third but the kernel is bound by CU-side delivery, not by HBM: tools/ab_wgrad.sh.  A 576-slot table that holds 7
+  //  ranges: 352 us -- some XCD then gets more than the 64 workgroups its 32 CUs take in two rounds)
   if (table_ok && R >= 2 && R <= 8 && R <= min_stages / 4 && max_blocks <= 63 && np <= 31) {
     // groups = (problem, row range); greedy: next group to the XCD with the fewest workgroups so far
     int len[8] = {0, 0, 0, 0, 0, 0, 0, 0};
