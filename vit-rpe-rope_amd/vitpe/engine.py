@@ -291,7 +291,9 @@ class TrainEngine:
             self.pe_grads["dfreqs"] = self.Gr(pe.freqs)
 
     # ---------------------------------------------------------------- forward / backward
-    def _forward(self, head=True):
+    def _forward(self, head=True, save=False):
+        """save: keep what backward needs of the MLP hidden layer (training); evaluation writes none of it."""
+        self._save_hidden = save
         mdl, B, N, D, M = self.model, self.B, self.N, self.D, self.M
         ape = mdl.pos_embed.pos_embed.data[0, :self.P] if isinstance(mdl.pos_embed, AbsolutePositionalEncoding) else None
         if self.fuse_embed:   # unfold + patch GEMM + bias + APE + class token + block 0's norm1 statistics: one kernel
@@ -364,13 +366,15 @@ class TrainEngine:
     def _block_tail_fwd(self, l, blk, a, nxt):
         M, D = self.M, self.D
         eps_next = self.model.blocks[min(l + 1, self.Lyr - 1)].norm1.eps
+        save = getattr(self, "_save_hidden", True)
         if self.tail2:   # wave-per-token-tile kernel on fragment-packed weights; keeps gelu'(u) in a["u"] instead of u
             K.block_tail2_fwd(a["a"].view(M, D), self.x[l].view(M, D), self.Fr(blk.attn.proj.weight),
                               blk.attn.proj.bias.data, blk.norm2.weight.data, blk.norm2.bias.data,
                               self.Fr(blk.mlp.fc1.weight), blk.mlp.fc1.bias.data, self.Fr(blk.mlp.fc2.weight),
                               blk.mlp.fc2.bias.data, x_mid=a["xmid"].view(M, D), mean2=a["m2"], rstd2=a["r2"],
-                              xn_out=(None if self.recompute_ln else a["xn2"].view(M, D)), gp=a["u"], h=a["h"],
-                              out=self.x[l + 1].view(M, D), stats=nxt, eps2=blk.norm2.eps, eps_next=eps_next)
+                              xn_out=(a["xn2"].view(M, D) if (save and not self.recompute_ln) else None),
+                              gp=(a["u"] if save else None), h=(a["h"] if save else None), out=self.x[l + 1].view(M, D),
+                              stats=nxt, eps2=blk.norm2.eps, eps_next=eps_next, save=save)
             return
         K.block_tail_fwd(a["a"].view(M, D), self.x[l].view(M, D), self.Sh(blk.attn.proj.weight),
                          blk.attn.proj.bias.data, blk.norm2.weight.data, blk.norm2.bias.data,
@@ -400,7 +404,7 @@ class TrainEngine:
         return (4 * M * D + 2 * M * hid) * es   # dy, x_mid in; d x_mid, d attn out; u in, du out
 
     def _fwd_train(self):
-        self._forward(head=not self.fuse_head)
+        self._forward(head=not self.fuse_head, save=True)
 
     def _loss(self, tick=True):
         """tick: this loss belongs to a full step -- the fused head launch also advances the optimizer's step counter."""
