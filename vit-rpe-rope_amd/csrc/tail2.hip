@@ -31,6 +31,7 @@
 // row index for loads AND stores: identical values written to the same address), so there is no guarded path.
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 #ifndef T2_NT_HID
 #define T2_NT_HID true
@@ -65,6 +66,7 @@ struct Tail2Args {
   float* mean_out;      // statistics of the output rows (next norm1), nullable (both or neither)
   float* rstd_out;
   int M, HID;
+  int nosplit;          // A/B: 1 = the ninth tile of a nine-tile workgroup stays on one wave (VITPE_T2_NOSPLIT)
   float eps2, eps_next;
   unsigned long long* census;   // CENSUS instantiation only (include/vitpe_debug.h)
 };
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(T2F_THREADS) void block_tail2_fwd_kernel(Tail2Args 
   // two compute waves and no loader): both run the proj + LayerNorm2 prologue for the tile, wave 8 then takes the even
   // 64-wide hidden chunks and wave 11 the odd ones (fc1 + GELU of chunk p while slab p is resident, fc2 of chunk p under
   // slab p + 1), and wave 11's partial fc2 sums reach wave 8 through a slab buffer that has gone idle.
-  const bool split = ntile_wg == T2_WAVES;
+  const bool split = ntile_wg == T2_WAVES && !a.nosplit;
   const int half = !split ? -1 : wave == T2_WAVES - 1 ? 0 : wave == T2_WAVES + 2 ? 1 : -1;   // -1: a whole tile
   const bool active = wave < ntile_wg || half == 1;           // wave-uniform
   const int nsig = ntile_wg + (split ? 1 : 0);                // compute waves that count themselves into sDone[]
@@ -1012,6 +1014,7 @@ static int tail2_launch(int dtype, const void* attn_out, const void* x_in, const
   if (ntiles <= 256 * 8) grid = (ntiles + 7) / 8;
   else grid = 256 * ((ntiles + 256 * T2_WAVES - 1) / (256 * T2_WAVES));
   a.census = census;
+  { static const bool ns = getenv("VITPE_T2_NOSPLIT") != nullptr; a.nosplit = ns ? 1 : 0; }
   if (census != nullptr) {
     VITPE_REQUIRE(gp_out != nullptr);
     if (exp == 1) hipLaunchKernelGGL((block_tail2_fwd_kernel<true, true, 1>), dim3(grid), dim3(T2F_THREADS), 0, stream, a);
