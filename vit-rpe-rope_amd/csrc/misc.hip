@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const T* __restrict__ x,
 //   * rows 1.. of dx are NOT written: the caller keeps them zero (they never change), only the class row is stored.
 // Batch totals: every wave leaves (loss, correct) of its image in per_image [B,2]; head_bwd_params_kernel, which follows
 // anyway, sums them in fixed order into out2 / metric_acc (deterministic, no atomics).
-template <typename T, int KD>
+template <typename T, int KD, bool WLDS>
 __global__ __launch_bounds__(256) void head_step_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ Wh,
                                                         const float* __restrict__ bh, const long long* __restrict__ labels,
@@ -401,9 +401,15 @@ __global__ __launch_bounds__(256) void head_step_kernel(const T* __restrict__ x,
                                                         float* __restrict__ ws_dyn, T* __restrict__ dx,
                                                         float* __restrict__ per_image, const float* __restrict__ ctl,
                                                         int B, int Ntok, int D, int Cn, float eps) {
+  // The head weight is read twice by every wave (logits, then the class row's gradient); from global those were 2 x Cn
+  // dependent L2 round trips in a one-wave-per-image chain.  Staged into LDS once per workgroup, under the HBM latency
+  // of the class rows (heads up to HS_LDS floats; larger ones keep reading global).
+  constexpr int HS_LDS = 16 * 768;
+  __shared__ float sWh[WLDS ? HS_LDS : 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.x * 4 + wave;
-  if (b >= B) return;
+  const int b_raw = blockIdx.x * 4 + wave;
+  const bool live = b_raw < B;
+  const int b = live ? b_raw : B - 1;
   const float invD = 1.0f / (float)D;
   const float gscale = ctl[0], lscale = ctl[1];
   const int nvalid = min(B, (int)ctl[2]);
@@ -417,8 +423,13 @@ __global__ __launch_bounds__(256) void head_step_kernel(const T* __restrict__ x,
     xv[k] = ok ? to_f32(row[d]) : 0.f;
     gam[k] = ok ? gamma[d] : 0.f;
     bet[k] = ok ? beta[d] : 0.f;
-    s += xv[k];
   }
+  if (WLDS)
+    for (int i = threadIdx.x; i < Cn * D; i += 256) sWh[i] = Wh[i];
+  __syncthreads();
+  if (!live) return;
+#pragma unroll
+  for (int k = 0; k < KD; ++k) s += xv[k];
   const float mean = wave_sum(s) * invD;
   float s2 = 0.f;
 #pragma unroll
@@ -442,7 +453,7 @@ __global__ __launch_bounds__(256) void head_step_kernel(const T* __restrict__ x,
 #pragma unroll
       for (int k = 0; k < KD; ++k) {
         const int d = lane + 64 * k;
-        part[j] += (d < D) ? yn[k] * Wh[(size_t)cI * D + d] : 0.f;
+        part[j] += (d < D) ? yn[k] * (WLDS ? sWh[cI * D + d] : Wh[(size_t)cI * D + d]) : 0.f;
       }
     }
 #pragma unroll
@@ -476,7 +487,7 @@ __global__ __launch_bounds__(256) void head_step_kernel(const T* __restrict__ x,
 #pragma unroll
     for (int k = 0; k < KD; ++k) {
       const int d = lane + 64 * k;
-      dyn[k] += (d < D) ? dc * Wh[(size_t)c * D + d] : 0.f;
+      dyn[k] += (d < D) ? dc * (WLDS ? sWh[c * D + d] : Wh[(size_t)c * D + d]) : 0.f;
     }
   }
   float t1 = 0.f, t2 = 0.f;
@@ -932,8 +943,14 @@ static int head_step_launch(const T* x, const float* gamma, const float* beta, c
                             float eps, hipStream_t st) {
   const dim3 grid((B + 3) / 4), block(256);
 #define VITPE_HEAD_STEP(KD)                                                                                              \
-  hipLaunchKernelGGL((head_step_kernel<T, KD>), grid, block, 0, st, x, gamma, beta, Wh, bh, labels, logits, dlogits,    \
-                     ws_xhat, ws_yn, ws_dyn, dx, per_image, ctl, B, Ntok, D, Cn, eps)
+  do {                                                                                                                   \
+    if (Cn * D <= 16 * 768)                                                                                              \
+      hipLaunchKernelGGL((head_step_kernel<T, KD, true>), grid, block, 0, st, x, gamma, beta, Wh, bh, labels, logits,    \
+                         dlogits, ws_xhat, ws_yn, ws_dyn, dx, per_image, ctl, B, Ntok, D, Cn, eps);                      \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((head_step_kernel<T, KD, false>), grid, block, 0, st, x, gamma, beta, Wh, bh, labels, logits,   \
+                         dlogits, ws_xhat, ws_yn, ws_dyn, dx, per_image, ctl, B, Ntok, D, Cn, eps);                      \
+  } while (0)
   const int kd = (D + 63) / 64;
   if (kd <= 2) VITPE_HEAD_STEP(2);
   else if (kd == 3) VITPE_HEAD_STEP(3);
