@@ -142,7 +142,7 @@ int vitpe_linear_lnbwd(int dtype, const void* dY, const void* Wt, void* dx, cons
                        const float* rstd, const float* gamma, const void* dres, float* dgamma, float* dbeta,
                        int M, int K, vitpe_stream_t stream);
 /* vitpe_linear_lnbwd2: the same function on the wave-per-tile mapping of vitpe_block_tail2_*, with the weight given as
- * Wt_packed = vitpe_pack_weight_frags(W^T [192,K], kchunk 192, phi 0), W = the Linear's weight [K,192] (attn.qkv.weight:
+ * Wt_packed = vitpe_pack_weight_frags(W^T [192,K], kchunk 64, phi 0), W = the Linear's weight [K,192] (attn.qkv.weight:
  * K = 576).  bf16, K % 192 == 0; otherwise hipErrorNotSupported.                                                        */
 int vitpe_linear_lnbwd2(int dtype, const void* dY, const void* Wt_packed, void* dx, const void* x, const float* mean,
                         const float* rstd, const float* gamma, const void* dres, float* dgamma, float* dbeta, int M,
@@ -194,12 +194,23 @@ int vitpe_block_tail2_fwd(int dtype, const void* attn_out, const void* x_in, con
  *   da = dx_mid attn.proj.weight  [M,192] (input of the attention backward);  dgamma / dbeta of norm2 accumulated (fp32
  *   atomics, one per column and workgroup).  gp = gelu'(u) as saved by vitpe_block_tail2_fwd; x_mid / mean2 / rstd2 its
  *   LayerNorm2 input rows and statistics.  Weights as vitpe_pack_weight_frags copies of the TRANSPOSES:
- *   W2t_packed = pack(fc2.weight^T [HID,192], kchunk 192, phi 0), W1t_packed = pack(fc1.weight^T [192,HID], kchunk 32, phi 1),
+ *   W2t_packed = pack(fc2.weight^T [HID,192], kchunk 192, phi 1), W1t_packed = pack(fc1.weight^T [192,HID], kchunk 32, phi 1),
  *   WpT_packed = pack(attn.proj.weight^T [192,192], kchunk 192, phi 1).  Support as vitpe_block_tail2_fwd.                 */
 int vitpe_block_tail2_bwd(int dtype, const void* dy, const void* gp, const void* W2t_packed, const void* W1t_packed,
                           const void* x_mid, const float* mean2, const float* rstd2, const float* gamma, void* du,
                           void* dx_mid, float* dgamma, float* dbeta, const void* WpT_packed, void* da, int M, int D,
                           int HID, vitpe_stream_t stream);
+/* vitpe_block_tail2_bwd_pre: the same preceded, in the same kernel, by the qkv data gradient + LayerNorm1 backward + residual
+ * of the block ABOVE (vitpe_linear_lnbwd2's function):  dy_out = dres1 + LayerNorm1'(d_qkv Wqkv)  is written (the weight
+ * gradients read it) and feeds the MLP backward from registers -- one launch, one HBM round trip of dy and one kernel
+ * prologue less per layer.  WqT_packed = pack(attn.qkv.weight^T [192,K1], kchunk 64, phi 0) of the upper block; x1 / mean1 /
+ * rstd1 / gamma1: its LayerNorm1 input rows, statistics and weight; dgamma1 / dbeta1 accumulated.  K1 % 64 == 0, K1 <= 640. */
+int vitpe_block_tail2_bwd_pre(int dtype, const void* d_qkv, const void* WqT_packed, const void* x1, const float* mean1,
+                              const float* rstd1, const float* gamma1, const void* dres1, float* dgamma1, float* dbeta1,
+                              int K1, void* dy_out, const void* gp, const void* W2t_packed, const void* W1t_packed,
+                              const void* x_mid, const float* mean2, const float* rstd2, const float* gamma, void* du,
+                              void* dx_mid, float* dgamma, float* dbeta, const void* WpT_packed, void* da, int M, int D,
+                              int HID, vitpe_stream_t stream);
 /* vitpe_mlp_bwd: backward of that branch w.r.t. its input, same pipeline on the transposed weight shadows:
  *   du = (dy fc2.weight) * gelu'(u)   [M,HID], stored (the fc1 weight gradient reads it)
  *   dx = dy + LayerNorm'(du fc1.weight) ; dgamma / dbeta accumulated (fp32 atomics)

@@ -430,7 +430,7 @@ def test_block_tail2_backward_equals_first_generation_on_saved_derivative(K, M, 
     w2, w1, wp = rnd(D, HID, seed=45, scale=0.05), rnd(HID, D, seed=46, scale=0.08), rnd(D, D, seed=47, scale=0.07)
     xd = dev(x, bf)
     _, mean, rstd = K.layernorm_fwd(xd, dev(g), torch.zeros(D, device="cuda"))
-    w2t_pk = K.pack_weight_frags(dev(w2.t().contiguous()), bf, 192, 0)
+    w2t_pk = K.pack_weight_frags(dev(w2.t().contiguous()), bf, 192, 1)
     w1t_pk = K.pack_weight_frags(dev(w1.t().contiguous()), bf, 32, 1)
     wpt_pk = K.pack_weight_frags(dev(wp.t().contiguous()), bf, 192, 1)
     dg2, db2 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
@@ -466,7 +466,7 @@ def test_linear_lnbwd2_equals_first_generation(K, M, Kd):
     xd = dev(x, bf)
     _, mean, rstd = K.layernorm_fwd(xd, dev(g), torch.zeros(D, device="cuda"))
     dg2, db2 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
-    dx2 = K.linear_lnbwd2(dev(dy, bf), K.pack_weight_frags(dev(w.t().contiguous()), bf, 192, 0), xd, mean, rstd, dev(g),
+    dx2 = K.linear_lnbwd2(dev(dy, bf), K.pack_weight_frags(dev(w.t().contiguous()), bf, 64, 0), xd, mean, rstd, dev(g),
                           dev(dres, bf), dg2, db2)
     dg1, db1 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
     dx1 = K.linear_lnbwd(dev(dy, bf), dev(w.t().contiguous(), bf), xd, mean, rstd, dev(g), dev(dres, bf), dg1, db1)
@@ -479,6 +479,49 @@ def test_linear_lnbwd2_equals_first_generation(K, M, Kd):
     ref = q(dres, "bf16") + rs * (gy - gy.mean(1, keepdim=True) - xhat * (gy * xhat).mean(1, keepdim=True))
     assert rel_err(dx2.float().cpu(), ref) < 6e-3
     assert rel_err(dg2.cpu(), (dxn * xhat).sum(0)) < 2e-3 and rel_err(db2.cpu(), dxn.sum(0)) < 2e-3
+
+
+@pytest.mark.parametrize("M,HID,K1", [(650, 768, 576), (33280, 768, 576), (13, 128, 192), (16 * 300 + 5, 768, 384), (100, 256, 320), (40, 128, 64)])
+def test_block_tail2_backward_with_fused_qkv_gradient_prologue(K, M, HID, K1):
+    """vitpe_block_tail2_bwd_pre == vitpe_linear_lnbwd2 (the upper block's qkv data gradient + LayerNorm1 backward + residual)
+    followed by vitpe_block_tail2_bwd on its output: same dy, du, dx_mid, da and both pairs of LayerNorm gradients."""
+    D, bf = 192, torch.bfloat16
+    dq, wq = rnd(M, K1, seed=61), rnd(K1, D, seed=62, scale=0.06)
+    x1, g1, dres1 = rnd(M, D, seed=63), 1 + 0.1 * rnd(D, seed=64), rnd(M, D, seed=65)
+    xm, g2 = rnd(M, D, seed=66), 1 + 0.1 * rnd(D, seed=67)
+    gp = 0.5 + 0.6 * rnd(M, HID, seed=68)
+    w2, w1, wp = rnd(D, HID, seed=69, scale=0.05), rnd(HID, D, seed=70, scale=0.08), rnd(D, D, seed=71, scale=0.07)
+    x1d, xmd = dev(x1, bf), dev(xm, bf)
+    _, m1, r1 = K.layernorm_fwd(x1d, dev(g1), torch.zeros(D, device="cuda"))
+    _, m2, r2 = K.layernorm_fwd(xmd, dev(g2), torch.zeros(D, device="cuda"))
+    wqt_pk = K.pack_weight_frags(dev(wq.t().contiguous()), bf, 64, 0)
+    w2t_pk = K.pack_weight_frags(dev(w2.t().contiguous()), bf, 192, 1)
+    w1t_pk = K.pack_weight_frags(dev(w1.t().contiguous()), bf, 32, 1)
+    wpt_pk = K.pack_weight_frags(dev(wp.t().contiguous()), bf, 192, 1)
+    z = lambda: torch.zeros(D, device="cuda")  # noqa: E731
+    # the two launches
+    dg1a, db1a, dg2a, db2a = z(), z(), z(), z()
+    if K1 % 192 == 0:
+        dy_a = K.linear_lnbwd2(dev(dq, bf), wqt_pk, x1d, m1, r1, dev(g1), dev(dres1, bf), dg1a, db1a)
+    else:   # widths the stand-alone kernel does not take (it streams 192-wide slabs): the generic pair of launches
+        dxn = K.linear(dev(dq, bf), dev(wq.t().contiguous(), bf), None)
+        dy_a = K.layernorm_bwd(dxn, x1d, m1, r1, dev(g1), dg1a, db1a, dres=dev(dres1, bf))
+    dx_a, du_a, da_a = K.block_tail2_bwd(dy_a, dev(gp, bf), w2t_pk, w1t_pk, xmd, m2, r2, dev(g2), dg2a, db2a, wpt_pk)
+    # the fused launch
+    dg1b, db1b, dg2b, db2b = z(), z(), z(), z()
+    dy_b = torch.empty(M, D, device="cuda", dtype=bf)
+    dx_b, du_b, da_b = K.block_tail2_bwd_pre(dev(dq, bf), wqt_pk, x1d, m1, r1, dev(g1), dev(dres1, bf), dg1b, db1b, dy_b,
+                                             dev(gp, bf), w2t_pk, w1t_pk, xmd, m2, r2, dev(g2), dg2b, db2b, wpt_pk)
+    if K1 % 192 == 0:
+        assert torch.equal(dy_b.cpu(), dy_a.cpu())
+        assert torch.equal(du_b.cpu(), du_a.cpu()) and torch.equal(dx_b.cpu(), dx_a.cpu()) and torch.equal(da_b.cpu(), da_a.cpu())
+        tol = 1e-5                                          # fp32 atomics in a different order
+    else:                                                   # the generic pair rounds dxn to bf16 between its launches
+        for u_, v_ in ((dy_b, dy_a), (du_b, du_a), (dx_b, dx_a), (da_b, da_a)):
+            assert rel_err(u_.float().cpu(), v_.float().cpu()) < 1.5e-2
+        tol = 4e-3
+    for u_, v_ in ((dg1b, dg1a), (db1b, db1a), (dg2b, dg2a), (db2b, db2a)):
+        assert rel_err(u_.cpu(), v_.cpu()) < tol
 
 
 def test_fused_mlp_unsupported_is_an_error(K):

@@ -74,7 +74,7 @@ struct Tail2Args {
 constexpr int T2_D = 192, T2_NT = 12, T2_KS = 6, T2_WAVES = 9;   // compute waves per workgroup
 constexpr int T2_THREADS = 64 * (T2_WAVES + 2);                      // + two loader waves
 constexpr int T2F_THREADS = 64 * (T2_WAVES + 3);                     // forward: + the helper wave of a split ninth tile
-constexpr int T2_MAXHID = 1536, T2_NFLAG = T2_MAXHID / 64 + 2;
+constexpr int T2_MAXHID = 1536, T2_NFLAG = T2_MAXHID / 64 + 10;   // slab flags (+ the fused qkv-gradient slabs of the backward)
 constexpr int T2_CH = 64, T2_CNT = T2_CH / 16, T2_CKS = T2_CH / 32;   // hidden chunk per slab: output tiles of fc1, k steps of fc2
 constexpr int T2_HALF = T2_CNT * T2_KS;                               // 24 fragments of fc1, 24 of fc2 (12 x 2) per slab
 constexpr int T2_SLABF = 2 * T2_HALF;                                 // fragments per slab buffer
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(T2F_THREADS) void block_tail2_fwd_kernel(Tail2Args 
 // ---------------------------------------------------------------------------------------------------------------------
 // Backward of the block tail w.r.t. its inputs (the weight gradients are the grouped wgrad kernel's): the same pipeline on
 // the transposed weights.  Per 16-token tile, everything transposed ([feature][token] accumulators):
-//   dh  = dy W2            F1 stage: A = fc2.weight^T rows of the hidden sub-chunk (natural k order), B = dy fragments
+//   dh  = dy W2            F1 stage: A = fc2.weight^T rows of the hidden sub-chunk (acc_to_frag k order), B = dy fragments
 //   du  = dh * gelu'(u)    G stage: gp rows loaded 2 sub-chunks ahead, du rows stored (fc1's weight gradient reads them)
 //   dxn = du W1            F2 stage: A = fc1.weight^T (k = hidden sub-chunk, acc_to_frag order), B = du fragments
 //   dx_mid = dy + LayerNorm2'(dxn)   (row statistics saved by the forward; dgamma / dbeta: DPP row sums over the 16 tokens,
@@ -571,7 +571,7 @@ struct Tail2BwdArgs {
   const float* mean2;   // [M]
   const float* rstd2;
   const float* gamma;   // norm2.weight [192]
-  const void* w2t;      // pack(fc2.weight^T [HID,192], kchunk 192, natural)
+  const void* w2t;      // pack(fc2.weight^T [HID,192], kchunk 192, phi)
   const void* w1t;      // pack(fc1.weight^T [192,HID], kchunk 32, phi)
   const void* wpt;      // pack(attn.proj.weight^T [192,192], kchunk 192, phi)
   void* du;             // [M,HID] out
@@ -580,6 +580,18 @@ struct Tail2BwdArgs {
   float* dgamma;        // [192] accumulated
   float* dbeta;
   int M, HID;
+  // PRE instantiation: the block ABOVE's qkv data gradient + LayerNorm1 backward + residual run first and PRODUCE dy
+  // (dy is then written by this kernel, for the weight gradients and its own LayerNorm2 residual, not read at the start)
+  const void* dqkv;     // [M,K1] gradient of that block's qkv projection
+  const void* wqt;      // pack(qkv.weight^T [192,K1], kchunk 64, natural)
+  const void* x1;       // [M,192] that block's input rows (LayerNorm1 input)
+  const float* mean1;
+  const float* rstd1;
+  const float* gamma1;
+  const void* dres1;    // [M,192] that block's d x_mid (residual)
+  float* dgamma1;
+  float* dbeta1;
+  int K1;
 };
 
 // inverse of t2_store_pair: lane (c, g) loads the 8 contiguous features it would have stored and gets back the two tiles'
@@ -684,17 +696,20 @@ VITPE_DEV void t2_flush_colsums(float* sAcc, int* sFin, int nactive, int lane, f
   }
 }
 
+template <bool PRE>
 __global__ __launch_bounds__(T2_THREADS) void block_tail2_bwd_kernel(Tail2BwdArgs a) {
   using T = bf16;
   constexpr int D = T2_D, NT = T2_NT, KS = T2_KS;
   __shared__ __attribute__((aligned(16))) T sW[3 * T2_SLABF * 512];
-  __shared__ __attribute__((aligned(16))) float sGam[T2_D];
-  __shared__ float sAcc[2 * T2_D];                    // dgamma | dbeta of this workgroup
+  __shared__ __attribute__((aligned(16))) float sGam[T2_D], sGam1[PRE ? T2_D : 4];
+  __shared__ float sAcc[2 * T2_D], sAcc1[PRE ? 2 * T2_D : 4];     // dgamma | dbeta of this workgroup (norm2; PRE: + the upper norm1)
   __shared__ int sReady[T2_NFLAG], sDone[T2_NFLAG], sFin;
 
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int HID = a.HID, nchunk = HID / T2_CH, nsub = 2 * nchunk;
+  // PRE: the qkv^T weight comes first, as Q slabs of two 64-deep k chunks (24 fragments each; the last slab may hold one)
+  const int nkc = PRE ? a.K1 / 64 : 0, Q = (nkc + 1) / 2, QB = nkc / 2;
   const int ntiles = (a.M + 15) / 16, base = ntiles / (int)gridDim.x, rem = ntiles % (int)gridDim.x;
   const int tile0 = (int)blockIdx.x * base + min((int)blockIdx.x, rem), ntile_wg = base + ((int)blockIdx.x < rem ? 1 : 0);
   const bool active = wave < ntile_wg;
@@ -704,25 +719,30 @@ __global__ __launch_bounds__(T2_THREADS) void block_tail2_bwd_kernel(Tail2BwdArg
 
   if (threadIdx.x < T2_NFLAG) { sReady[threadIdx.x] = 0; sDone[threadIdx.x] = 0; }
   if (threadIdx.x == 0) sFin = 0;
-  for (int i = threadIdx.x; i < 2 * D; i += T2_THREADS) sAcc[i] = 0.f;
-  for (int i = threadIdx.x; i < D; i += T2_THREADS) sGam[i] = a.gamma[i];
+  for (int i = threadIdx.x; i < 2 * D; i += T2_THREADS) { sAcc[i] = 0.f; if (PRE) sAcc1[i] = 0.f; }
+  for (int i = threadIdx.x; i < D; i += T2_THREADS) { sGam[i] = a.gamma[i]; if (PRE) sGam1[i] = a.gamma1[i]; }
 
   auto dma1 = [&](const T* src_frag, int dst_frag) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_frag + lane * 8),
                                      (__attribute__((address_space(3))) void*)(sW + dst_frag * 512), 16, 0, 0);
   };
-  // ---- waves 9 and 10: the loaders (see the forward kernel): wave 9 the F1 halves of slabs 0 .. nchunk - 1 (fc2.weight^T),
-  // wave 10 the F2 halves of slabs 1 .. nchunk (fc1.weight^T); a half buffer is reused only by the same loader's slab s + 3.
-  // When every slab has been consumed both load their half of attn.proj.weight^T into fragments [0, 72).
+  // ---- waves 9 and 10: the loaders (see the forward kernel).  One sequence of slabs g = 0 .. Q + nchunk: the Q qkv^T slabs
+  // (PRE), then MLP slab s at g = Q + s (F1 half: fc2.weight^T rows of chunk s, F2 half: fc1.weight^T k chunk s - 1); slab g
+  // lives in buffer (g + 2) % 3, wave 9 moves the first 24 fragments of a slab, wave 10 the second 24 (where they exist).
+  // A slab may be issued once slab g - 3 has been consumed by every active wave (sDone[g - 2]).  When everything has
+  // been consumed both load their half of attn.proj.weight^T into fragments [0, 72).
   if (wave >= T2_WAVES) {
     const bool is1 = wave == T2_WAVES;
-    const int first = is1 ? 0 : 1, last = is1 ? nchunk - 1 : nchunk;
-    const T* const src = is1 ? reinterpret_cast<const T*>(a.w2t) : reinterpret_cast<const T*>(a.w1t) - (size_t)T2_HALF * 512;
+    const int nq = is1 ? Q : QB, njobs = nq + nchunk;
     const int half = is1 ? 0 : T2_HALF;
-    auto dma_half = [&](int sl) {
-      const int b0 = ((sl + 2) % 3) * T2_SLABF + half;
+    auto job_slab = [&](int j) { return j < nq ? j : Q + (j - nq) + (is1 ? 0 : 1); };
+    auto dma_job = [&](int j) {
+      const T* src;
+      if (j < nq) src = reinterpret_cast<const T*>(a.wqt) + ((size_t)j * T2_SLABF + half) * 512;
+      else src = (is1 ? reinterpret_cast<const T*>(a.w2t) : reinterpret_cast<const T*>(a.w1t)) + (size_t)(j - nq) * T2_HALF * 512;
+      const int b0 = ((job_slab(j) + 2) % 3) * T2_SLABF + half;
 #pragma unroll
-      for (int f = 0; f < T2_HALF; ++f) dma1(src + ((size_t)sl * T2_HALF + f) * 512, b0 + f);
+      for (int f = 0; f < T2_HALF; ++f) dma1(src + (size_t)f * 512, b0 + f);
     };
     auto wait_done = [&](int k) {
       while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sDone[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < ntile_wg)
@@ -735,30 +755,42 @@ __global__ __launch_bounds__(T2_THREADS) void block_tail2_bwd_kernel(Tail2BwdArg
     };
     __builtin_amdgcn_s_waitcnt(0x0070);         // lgkmcnt(0): the LDS initialisation above
     asm volatile("s_barrier" ::: "memory");     // the one barrier
-    dma_half(first);
-    if (first + 1 <= last) dma_half(first + 1);
-    for (int sl = first; sl <= last; ++sl) {
-      if (sl + 1 <= last) __builtin_amdgcn_s_waitcnt(0x4F78);   // vmcnt(24): only slab sl + 1's pieces may be in flight
-      else __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
-      raise(sl);
-      if (sl + 2 <= last) {
-        if (sl - 1 >= first) wait_done(sl);                     // sDone[sl] counts slab sl - 1, whose half buffer slab sl + 2 takes
-        dma_half(sl + 2);
+    // Two jobs in flight.  A job's buffer is free when slab g - 3 has been consumed (sDone[g - 2]) -- but this loader must have
+    // RAISED its own older slabs before it waits for them to be consumed (with the qkv slabs in front, wave 10's slab list
+    // jumps from 3 to Q + 1: waiting for slab 3 to be consumed before raising slab 3 is a deadlock).
+    int issued = 0, raised = 0;
+    auto top_up = [&]() {
+      while (issued < njobs && issued - raised < 2) {
+        const int g2 = job_slab(issued);
+        if (g2 >= 3) {
+          if (raised < issued && job_slab(raised) <= g2 - 3) break;        // raise that one first
+          wait_done(g2 - 2);
+        }
+        dma_job(issued++);
       }
+    };
+    top_up();
+    while (raised < njobs) {
+      if (issued - raised - 1 >= 1) __builtin_amdgcn_s_waitcnt(0x4F78);   // vmcnt(24): one younger job may be in flight
+      else __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0)
+      raise(job_slab(raised));
+      ++raised;
+      top_up();
     }
-    wait_done(nchunk + 1);                                      // every slab consumed by every active wave
+    wait_done(Q + nchunk + 1);                                 // every slab consumed by every active wave
 #pragma unroll
     for (int f = 0; f < NT * KS / 2; ++f) {
       const int ff = (is1 ? 0 : NT * KS / 2) + f;
       dma1(reinterpret_cast<const T*>(a.wpt) + (size_t)ff * 512, ff);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    raise(nchunk + 1);
+    raise(Q + nchunk + 1);
     return;
   }
-  auto wait_ready = [&](int sl) {
-    const int need = sl > nchunk ? 2 : (sl < nchunk ? 1 : 0) + (sl >= 1 ? 1 : 0);
-    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sReady[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need)
+  auto wait_ready = [&](int gs) {      // both halves (where they exist) of global slab gs have landed
+    const int s = gs - Q;
+    const int need = gs < Q ? 1 + (2 * gs + 1 < nkc ? 1 : 0) : s > nchunk ? 2 : (s < nchunk ? 1 : 0) + (s >= 1 ? 1 : 0);
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sReady[gs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need)
       __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
   };
@@ -766,17 +798,57 @@ __global__ __launch_bounds__(T2_THREADS) void block_tail2_bwd_kernel(Tail2BwdArg
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) atomicAdd(&sDone[k], 1);
   };
+  auto slab_ptr = [&](int gs) { return sW + ((gs + 2) % 3) * T2_SLABF * 512 + lane * 8; };
 
-  // ---- compute waves: dy rows as B fragments (natural k order) --------------------------------------------------------------
+  // ---- compute waves -------------------------------------------------------------------------------------------------------
   Frag<T> bf[KS];
+  const T* const dqr = PRE ? reinterpret_cast<const T*>(a.dqkv) + (size_t)rowc * a.K1 + 8 * g : nullptr;
+  Frag<T> bqa[4], bqb[4];       // PRE: this wave's d_qkv rows as B fragments (natural k order), four 32-deep steps per slab
   if (active) {
-    const T* dr = reinterpret_cast<const T*>(a.dy) + (size_t)rowc * D + 8 * g;
+    if (PRE) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) bf[ks] = ld_frag(dr + 32 * ks);
+      for (int i = 0; i < 4; ++i) bqa[i] = ld_frag(dqr + 32 * min(i, a.K1 / 32 - 1));
+    } else {
+      // dy rows as B fragments in the acc_to_frag k order (what the PRE path produces from its accumulators)
+      const T* dr = reinterpret_cast<const T*>(a.dy) + (size_t)rowc * D + 4 * g;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(dr + 32 * ks), hi = *reinterpret_cast<const bf16x4*>(dr + 32 * ks + 16);
+        bf[ks].v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    }
   }
   __builtin_amdgcn_s_waitcnt(0x0070);           // vmcnt(0) lgkmcnt(0)
   asm volatile("s_barrier" ::: "memory");       // the one barrier
   if (!active) return;
+
+  if (PRE) {
+    // ---- the upper block's  dy = d x_mid' + LayerNorm1'(d_qkv Wqkv)  (vitpe_linear_lnbwd2's work), kept in registers -----------
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nks = a.K1 / 32;
+    auto qslab = [&](int q, const Frag<T> (&cur)[4], Frag<T> (&nxt)[4]) {
+      if (q + 1 < Q) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) nxt[i] = ld_frag(dqr + 32 * min(4 * (q + 1) + i, nks - 1));
+      }
+      wait_ready(q);
+      const T* wb = slab_ptr(q);
+      t2_gemm<NT, 2, 8>(wb, cur, acc);
+      if (4 * q + 2 < nks) t2_gemm<NT, 2, 8>(wb + T2_HALF * 512, cur + 2, acc);
+      signal_done(q + 1);
+    };
+    for (int q = 0; q < Q; q += 2) {
+      qslab(q, bqa, bqb);
+      if (q + 1 < Q) qslab(q + 1, bqb, bqa);
+    }
+    t2_ln_backward(acc, reinterpret_cast<const T*>(a.x1) + (size_t)rowc * D + 4 * g,
+                   reinterpret_cast<const T*>(a.dres1) + (size_t)rowc * D + 4 * g, a.mean1[rowc], a.rstd1[rowc], sGam1, sAcc1,
+                   c, g, valid, reinterpret_cast<T*>(const_cast<void*>(a.dy)) + (size_t)rowc * D);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bf[ks] = acc_to_frag<T>(acc[2 * ks], acc[2 * ks + 1]);
+  }
 
   const T* const gpr = reinterpret_cast<const T*>(a.gp) + (size_t)rowc * HID + 16 * (g & 1) + 8 * (g >> 1);
   T* const dur = reinterpret_cast<T*>(a.du) + (size_t)rowc * HID;
@@ -801,32 +873,32 @@ __global__ __launch_bounds__(T2_THREADS) void block_tail2_bwd_kernel(Tail2BwdArg
   };
   constexpr int NVB = 3, RB = T2_RB;    // VALU instructions of the G stage per MFMA (it is short: the step is matrix-pipe bound)
 
-  wait_ready(0);
+  wait_ready(Q);
   {
-    const T* wb = sW + 2 * T2_SLABF * 512 + lane * 8;
+    const T* wb = slab_ptr(Q);
     aX[0] = z4; aX[1] = z4;
     t2_step<true, false, 0, 0, RB>(wb, wb, bf, aX, hQ, acc2, [&]() {});                                             // F1_0
     aY[0] = z4; aY[1] = z4;
     t2_step<true, false, 2 * NVB, 0, RB>(wb + 2 * KS * 512, wb, bf, aY, hQ, acc2, [&]() { gstage(aX, gq[0], 0, hP); });   // F1_1 G_0
-    signal_done(1);
+    signal_done(Q + 1);
   }
   for (int p = 1; p < nchunk; ++p) {
-    wait_ready(p);
-    const T* wb = sW + ((p + 2) % 3) * T2_SLABF * 512 + lane * 8;
+    wait_ready(Q + p);
+    const T* wb = slab_ptr(Q + p);
     const T* w2b = wb + T2_HALF * 512;
     aX[0] = z4; aX[1] = z4;
     t2_step<true, true, NVB, 0, RB>(wb, w2b, bf, aX, hP, acc2, [&]() { gstage(aY, gq[1], 2 * p - 1, hQ); });
     aY[0] = z4; aY[1] = z4;
     t2_step<true, true, NVB, 0, RB>(wb + 2 * KS * 512, w2b + NT * 512, bf, aY, hQ, acc2, [&]() { gstage(aX, gq[0], 2 * p, hP); });
-    signal_done(p + 1);
+    signal_done(Q + p + 1);
   }
-  wait_ready(nchunk);
+  wait_ready(Q + nchunk);
   {
-    const T* w2b = sW + ((nchunk + 2) % 3) * T2_SLABF * 512 + T2_HALF * 512 + lane * 8;
+    const T* w2b = slab_ptr(Q + nchunk) + T2_HALF * 512;
     const int tl = nsub - 1;
     t2_step<false, true, 2 * NVB, 0, RB>(w2b, w2b, bf, aX, hP, acc2, [&]() { gstage(aY, gq[1], tl, hQ); });
     t2_step<false, true, 0, 0, RB>(w2b, w2b + NT * 512, bf, aX, hQ, acc2, [&]() {});                                  // F2_last
-    signal_done(nchunk + 1);
+    signal_done(Q + nchunk + 1);
   }
   // ---- LayerNorm2 backward + residual: dx_mid = dy + LayerNorm2'(dxn) ------------------------------------------------------------
   t2_ln_backward(acc2, reinterpret_cast<const T*>(a.xmid) + (size_t)rowc * D + 4 * g,
@@ -838,25 +910,39 @@ __global__ __launch_bounds__(T2_THREADS) void block_tail2_bwd_kernel(Tail2BwdArg
   f32x4 accA[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) accA[nt] = z4;
-  wait_ready(nchunk + 1);
+  wait_ready(Q + nchunk + 1);
   t2_gemm<NT, KS, 12>(sW + lane * 8, bf, accA);
   {
     T* const dar = reinterpret_cast<T*>(a.da) + (size_t)rowc * D;
 #pragma unroll
     for (int nt = 0; nt < NT; nt += 2) t2_store_pair<false>(dar, nt, g, accA[nt], accA[nt + 1]);
   }
-  t2_flush_colsums(sAcc, &sFin, ntile_wg, lane, a.dgamma, a.dbeta);
+  // ---- the last wave of the workgroup hands the column sums to the global accumulators ----------------------------------------
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  int fin = 0;
+  if (lane == 0) fin = atomicAdd(&sFin, 1);
+  fin = __builtin_amdgcn_readfirstlane(fin);
+  if (fin == ntile_wg - 1) {
+    for (int i = lane; i < D; i += 64) {
+      atomicAdd(a.dgamma + i, __hip_atomic_load(&sAcc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      atomicAdd(a.dbeta + i, __hip_atomic_load(&sAcc[D + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      if (PRE) {
+        atomicAdd(a.dgamma1 + i, __hip_atomic_load(&sAcc1[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        atomicAdd(a.dbeta1 + i, __hip_atomic_load(&sAcc1[D + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // dx = dres + LayerNorm'(dY Wt^T): the data gradient of a Linear whose input is a LayerNorm output, that LayerNorm's
 // backward, and the residual add (attn.qkv: dY = d_qkv [M,576], LayerNorm1, dres = d x_mid) -- the wave-per-tile mapping of
-// the kernels above.  Wt packed = pack(weight^T [192, K], kchunk 192, natural): K / 192 slabs of 72 fragments, two LDS
+// the kernels above.  Wt packed = pack(weight^T [192, K], kchunk 64, natural): K / 192 slabs of 72 fragments, two LDS
 // buffers, the two loader waves each move half a slab; a compute wave loads its 16 dY rows as B fragments straight from
 // global, one 192-wide k chunk ahead of the product.
 struct LnBwd2Args {
   const void* dy;       // [M,K]
-  const void* wt;       // pack(W^T [192,K], 192, natural)
+  const void* wt;       // pack(W^T [192,K], 64, natural)
   const void* x;        // [M,192] LayerNorm input rows
   const float* mean;
   const float* rstd;
@@ -938,7 +1024,11 @@ __global__ __launch_bounds__(T2_THREADS) void ln_bwd2_kernel(LnBwd2Args a) {
     while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sReady[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < 2)
       __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
-    t2_gemm<NT, KS, 12>(sW + (sl & 1) * SLF * 512 + lane * 8, cur, acc);
+    {   // a 192-deep slab = three 64-deep k chunks of 24 fragments ((tile * 2 + k step) inside a chunk)
+      const T* wb = sW + (sl & 1) * SLF * 512 + lane * 8;
+#pragma unroll
+      for (int kcl = 0; kcl < 3; ++kcl) t2_gemm<NT, 2, 8>(wb + kcl * T2_HALF * 512, cur + 2 * kcl, acc);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) atomicAdd(&sDone[sl], 1);
   };
@@ -1052,8 +1142,18 @@ extern "C" int vitpe_debug_tail2_census(const void* attn_out, const void* x_in, 
 
 // Backward of vitpe_block_tail2_fwd w.r.t. its inputs: du [M,HID] (fc1's weight gradient reads it), dx_mid [M,192], da [M,192]
 // (the attention backward's input); dgamma / dbeta of norm2 accumulated.  Weights as packed copies of the TRANSPOSES:
-// W2t_packed = pack(fc2.weight^T [HID,192], 192, 0), W1t_packed = pack(fc1.weight^T [192,HID], 32, 1),
+// W2t_packed = pack(fc2.weight^T [HID,192], 192, 1), W1t_packed = pack(fc1.weight^T [192,HID], 32, 1),
 // WpT_packed = pack(attn.proj.weight^T [192,192], 192, 1).
+static int tail2_bwd_launch(const Tail2BwdArgs& a0, bool pre, hipStream_t stream) {
+  Tail2BwdArgs a = a0;
+  const int ntiles = (a.M + 15) / 16;
+  int grid;
+  if (ntiles <= 256 * 8) grid = (ntiles + 7) / 8;
+  else grid = 256 * ((ntiles + 256 * T2_WAVES - 1) / (256 * T2_WAVES));
+  if (pre) hipLaunchKernelGGL(block_tail2_bwd_kernel<true>, dim3(grid), dim3(T2_THREADS), 0, stream, a);
+  else hipLaunchKernelGGL(block_tail2_bwd_kernel<false>, dim3(grid), dim3(T2_THREADS), 0, stream, a);
+  VITPE_CHECK_LAUNCH();
+}
 extern "C" int vitpe_block_tail2_bwd(int dtype, const void* dy, const void* gp, const void* W2t_packed, const void* W1t_packed,
                                      const void* x_mid, const float* mean2, const float* rstd2, const float* gamma, void* du,
                                      void* dx_mid, float* dgamma, float* dbeta, const void* WpT_packed, void* da, int M, int D,
@@ -1065,15 +1165,32 @@ extern "C" int vitpe_block_tail2_bwd(int dtype, const void* dy, const void* gp, 
   Tail2BwdArgs a{};
   a.dy = dy; a.gp = gp; a.xmid = x_mid; a.mean2 = mean2; a.rstd2 = rstd2; a.gamma = gamma; a.w2t = W2t_packed; a.w1t = W1t_packed;
   a.wpt = WpT_packed; a.du = du; a.dxmid = dx_mid; a.da = da; a.dgamma = dgamma; a.dbeta = dbeta; a.M = M; a.HID = HID;
-  const int ntiles = (M + 15) / 16;
-  int grid;
-  if (ntiles <= 256 * 8) grid = (ntiles + 7) / 8;
-  else grid = 256 * ((ntiles + 256 * T2_WAVES - 1) / (256 * T2_WAVES));
-  hipLaunchKernelGGL(block_tail2_bwd_kernel, dim3(grid), dim3(T2_THREADS), 0, stream, a);
-  VITPE_CHECK_LAUNCH();
+  return tail2_bwd_launch(a, false, stream);
+}
+// The same with the block ABOVE's qkv data gradient + LayerNorm1 backward + residual (vitpe_linear_lnbwd2's function) run
+// first in the same kernel: dy_out = dres1 + LayerNorm1'(d_qkv Wqkv) is WRITTEN (the weight gradients read it) and feeds the
+// MLP backward from registers.  WqT_packed = pack(attn.qkv.weight^T [192,K1], kchunk 64, phi 0) of the upper block; x1 / mean1 /
+// rstd1 / gamma1 its LayerNorm1 input rows, statistics and weight; dgamma1 / dbeta1 accumulated.  K1 % 64 == 0, K1 <= 640.
+extern "C" int vitpe_block_tail2_bwd_pre(int dtype, const void* d_qkv, const void* WqT_packed, const void* x1, const float* mean1,
+                                         const float* rstd1, const float* gamma1, const void* dres1, float* dgamma1,
+                                         float* dbeta1, int K1, void* dy_out, const void* gp, const void* W2t_packed,
+                                         const void* W1t_packed, const void* x_mid, const float* mean2, const float* rstd2,
+                                         const float* gamma, void* du, void* dx_mid, float* dgamma, float* dbeta,
+                                         const void* WpT_packed, void* da, int M, int D, int HID, hipStream_t stream) {
+  VITPE_REQUIRE(d_qkv && WqT_packed && x1 && mean1 && rstd1 && gamma1 && dres1 && dgamma1 && dbeta1 && dy_out && gp &&
+                W2t_packed && W1t_packed && x_mid && mean2 && rstd2 && gamma && du && dx_mid && dgamma && dbeta && WpT_packed &&
+                da && M >= 0);
+  if (!vitpe_block_tail2_supported(dtype, D, HID) || K1 <= 0 || K1 % 64 != 0 || K1 > 640) return (int)hipErrorNotSupported;
+  if (M == 0) return 0;
+  Tail2BwdArgs a{};
+  a.dy = dy_out; a.gp = gp; a.xmid = x_mid; a.mean2 = mean2; a.rstd2 = rstd2; a.gamma = gamma; a.w2t = W2t_packed;
+  a.w1t = W1t_packed; a.wpt = WpT_packed; a.du = du; a.dxmid = dx_mid; a.da = da; a.dgamma = dgamma; a.dbeta = dbeta; a.M = M;
+  a.HID = HID; a.dqkv = d_qkv; a.wqt = WqT_packed; a.x1 = x1; a.mean1 = mean1; a.rstd1 = rstd1; a.gamma1 = gamma1; a.dres1 = dres1;
+  a.dgamma1 = dgamma1; a.dbeta1 = dbeta1; a.K1 = K1;
+  return tail2_bwd_launch(a, true, stream);
 }
 
-// dx = dres + LayerNorm'(dY W) with Wt_packed = pack(W^T [192,K], kchunk 192, natural) (W = the Linear's weight [K,192], e.g.
+// dx = dres + LayerNorm'(dY W) with Wt_packed = pack(W^T [192,K], kchunk 64, natural) (W = the Linear's weight [K,192], e.g.
 // attn.qkv.weight): vitpe_linear_lnbwd on the wave-per-tile mapping.  bf16, K % 192 == 0, K <= 192 * 24.
 extern "C" int vitpe_linear_lnbwd2(int dtype, const void* dY, const void* Wt_packed, void* dx, const void* x, const float* mean,
                                    const float* rstd, const float* gamma, const void* dres, float* dgamma, float* dbeta, int M,

@@ -85,6 +85,8 @@ class TrainEngine:
         # qkv data gradient + LayerNorm1 backward on the same mapping (29.5 vs 31.4 us for the panel kernel; VITPE_LNBWD2=0:
         # the panel kernel on the transposed shadow)
         self.lnbwd2 = self.tail2 and self.tail2_bwd and os.environ.get("VITPE_LNBWD2", "1") == "1"
+        # ... and run as the PROLOGUE of the block below's tail backward (one kernel per layer boundary; VITPE_FUSE_LNBWD=0: two)
+        self.fuse_lnbwd = self.lnbwd2 and os.environ.get("VITPE_FUSE_LNBWD", "1") == "1"
         self._build_flat(lr, weight_decay, betas, eps)
         self._build_buffers()
         # gradient exchange in two buckets so the first overlaps the lower half of the backward pass:
@@ -151,13 +153,13 @@ class TrainEngine:
             # kind 0 transposed shadow (first-generation data-gradient GEMMs), 1 qkv pack (attention), 2 / 3 fragment packs
             # (block_tail2_fwd), 4 / 5 fragment packs of the transposes (block_tail2_bwd, linear_lnbwd2)
             if self.attn_fused:
-                add(qkv, 1, HDh, *((4, 192) if self.lnbwd2 else (0, 0)))
+                add(qkv, 1, HDh, *((4, 64) if self.lnbwd2 else (0, 0)))
             else:
                 add(qkv, 0, 0)
             if self.tail2:
                 add(proj, 2, 192, *((5, 192) if gen2 else (0, 0)))
                 add(fc1, 3, 192, *((5, 32) if gen2 else (0, 0)))
-                add(fc2, 3, 32, *((4, 192) if gen2 else (0, 0)))
+                add(fc2, 3, 32, *((5, 192) if gen2 else (0, 0)))
             else:
                 for w in (proj, fc1, fc2):
                     add(w, 0, 0)
@@ -383,8 +385,19 @@ class TrainEngine:
                          xn_out=(None if self.recompute_ln else a["xn2"].view(M, D)), u=a["u"], h=a["h"],
                          out=self.x[l + 1].view(M, D), stats=nxt, eps2=blk.norm2.eps, eps_next=eps_next)
 
-    def _block_tail_bwd(self, l, blk, a):
+    def _block_tail_bwd(self, l, blk, a, pre=False):
+        """pre: the qkv data gradient + LayerNorm1 backward of block l + 1 run first in the same kernel and produce
+        dx_out[l + 1] (this block's dy)."""
         M, D, G = self.M, self.D, self.Gr
+        if pre:
+            up, ua = self.model.blocks[l + 1], self.act[l + 1]
+            K.block_tail2_bwd_pre(self.dqkv_l[l + 1].view(M, 3 * D), self.Frt(up.attn.qkv.weight), self.x[l + 1].view(M, D),
+                                  ua["m1"], ua["r1"], up.norm1.weight.data, self.dx_mid[l + 1].view(M, D), G(up.norm1.weight),
+                                  G(up.norm1.bias), self.dx_out[l + 1].view(M, D), a["u"], self.Frt(blk.mlp.fc2.weight),
+                                  self.Frt(blk.mlp.fc1.weight), a["xmid"].view(M, D), a["m2"], a["r2"], blk.norm2.weight.data,
+                                  G(blk.norm2.weight), G(blk.norm2.bias), self.Frt(blk.attn.proj.weight), du=self.du_l[l],
+                                  out=self.dx_mid[l].view(M, D), da=self.dtmp.view(M, D))
+            return
         if self.tail2 and self.tail2_bwd:
             K.block_tail2_bwd(self.dx_out[l + 1].view(M, D), a["u"], self.Frt(blk.mlp.fc2.weight), self.Frt(blk.mlp.fc1.weight),
                               a["xmid"].view(M, D), a["m2"], a["r2"], blk.norm2.weight.data, G(blk.norm2.weight),
@@ -492,7 +505,8 @@ class TrainEngine:
             fc1_wgrad = lambda: K.gemm_tn(du, a["xn2"].view(M, D), G(blk.mlp.fc1.weight), G(blk.mlp.fc1.bias))  # noqa: E731
             tail_done = False
             if self.fuse_mlp and self.fuse_ln_bwd and self.fuse_tail:   # ... + the projection's data gradient
-                self._block_tail_bwd(l, blk, a)
+                self._block_tail_bwd(l, blk, a, pre=(self.fuse_lnbwd and self.group_wgrad and l < hi))   # (+ block l + 1's qkv data gradient;
+                # per-GEMM weight gradients would read dy before the fused kernel has written it)
                 self._wgrad(ev(), fc1_wgrad)
                 tail_done = True
             elif self.fuse_mlp and self.fuse_ln_bwd:   # gelu' + both data gradients + LayerNorm2 backward + residual
@@ -527,7 +541,9 @@ class TrainEngine:
                 K.attention_core_bwd(self.qkv_l[l], self.dtmp, self.H, self.pe, out=dqkv, **self.pe_grads)
             e_dq = ev()
             self._wgrad(e_dq, lambda: K.gemm_tn(dqkv.view(M, 3 * D), a["xn1"].view(M, D), G(blk.attn.qkv.weight), None))
-            if self.fuse_ln_bwd and self.lnbwd2:   # ... on the wave-per-tile mapping, packed qkv.weight^T (opt-in)
+            if self.fuse_lnbwd and self.group_wgrad and l > lo:
+                pass   # runs as the prologue of block l - 1's tail backward (next iteration)
+            elif self.fuse_ln_bwd and self.lnbwd2:   # ... on the wave-per-tile mapping, packed qkv.weight^T
                 K.linear_lnbwd2(dqkv.view(M, 3 * D), self.Frt(blk.attn.qkv.weight), self.x[l].view(M, D), a["m1"],
                                 a["r1"], blk.norm1.weight.data, dm, G(blk.norm1.weight), G(blk.norm1.bias),
                                 out=self.dx_out[l].view(M, D))

@@ -83,7 +83,7 @@ def linear_lnbwd(dy, wt, x, mean, rstd, gamma, dres, dgamma, dbeta, out=None):
 
 
 def linear_lnbwd2(dy, wt_pk, x, mean, rstd, gamma, dres, dgamma, dbeta, out=None):
-    """linear_lnbwd on the wave-per-tile mapping; wt_pk = pack_weight_frags(weight^T [192,K], dtype, 192, 0)."""
+    """linear_lnbwd on the wave-per-tile mapping; wt_pk = pack_weight_frags(weight^T [192,K], dtype, 64, 0)."""
     require_device(dy, wt_pk, x, mean, rstd, gamma, dres, dgamma, dbeta, out)
     M, K = dy.shape
     assert wt_pk.numel() == 192 * K and x.shape[-1] == 192 and dy.dtype == wt_pk.dtype == x.dtype == dres.dtype
@@ -261,7 +261,7 @@ def block_tail_bwd(dy, u, w2t, w1t, x, mean, rstd, gamma, dgamma, dbeta, wpt, du
 
 def block_tail2_bwd(dy, gp, w2t_pk, w1t_pk, x_mid, mean2, rstd2, gamma, dgamma, dbeta, wpt_pk, du=None, out=None, da=None):
     """Backward of block_tail2_fwd w.r.t. its inputs on packed TRANSPOSED weights (pack_weight_frags of fc2.weight^T
-    (192, natural), fc1.weight^T (32, phi), proj.weight^T (192, phi)) -> (dx_mid, du, da); dgamma / dbeta accumulated."""
+    (192, phi), fc1.weight^T (32, phi), proj.weight^T (192, phi)) -> (dx_mid, du, da); dgamma / dbeta accumulated."""
     require_device(dy, gp, w2t_pk, w1t_pk, x_mid, mean2, rstd2, gamma, dgamma, dbeta, wpt_pk, du, out, da)
     M, D = dy.shape
     HID = gp.shape[1]
@@ -274,6 +274,30 @@ def block_tail2_bwd(dy, gp, w2t_pk, w1t_pk, x_mid, mean2, rstd2, gamma, dgamma, 
     check(lib().vitpe_block_tail2_bwd(dtype_code(dy.dtype), ptr(dy), ptr(gp), ptr(w2t_pk), ptr(w1t_pk), ptr(x_mid), ptr(mean2),
                                       ptr(rstd2), ptr(gamma), ptr(du), ptr(out), ptr(dgamma), ptr(dbeta), ptr(wpt_pk), ptr(da),
                                       M, D, HID, stream_ptr()), "vitpe_block_tail2_bwd")
+    return out, du, da
+
+
+def block_tail2_bwd_pre(dqkv, wqt_pk, x1, mean1, rstd1, gamma1, dres1, dgamma1, dbeta1, dy_out, gp, w2t_pk, w1t_pk, x_mid,
+                        mean2, rstd2, gamma, dgamma, dbeta, wpt_pk, du=None, out=None, da=None):
+    """block_tail2_bwd preceded in the same kernel by the upper block's linear_lnbwd2: dy_out = dres1 + LN1'(dqkv Wqkv) is
+    written and feeds the MLP backward from registers (wqt_pk = pack_weight_frags(qkv.weight^T, 64, 0))."""
+    require_device(dqkv, wqt_pk, x1, mean1, rstd1, gamma1, dres1, dgamma1, dbeta1, dy_out, gp, w2t_pk, w1t_pk, x_mid, mean2,
+                   rstd2, gamma, dgamma, dbeta, wpt_pk, du, out, da)
+    M, K1 = dqkv.shape
+    D, HID = dy_out.shape[1], gp.shape[1]
+    assert dy_out.shape == (M, D) and gp.shape == (M, HID) and x_mid.shape == (M, D) and wqt_pk.numel() == D * K1
+    assert dqkv.dtype == wqt_pk.dtype == dy_out.dtype == gp.dtype == w2t_pk.dtype == w1t_pk.dtype == x_mid.dtype == wpt_pk.dtype
+    for t_, n_ in ((gamma, "gamma"), (dgamma, "dgamma"), (dbeta, "dbeta"), (gamma1, "gamma1"), (dgamma1, "dgamma1"),
+                   (dbeta1, "dbeta1"), (mean1, "mean1"), (rstd1, "rstd1"), (mean2, "mean2"), (rstd2, "rstd2")):
+        _f32(t_, n_)
+    du = du if du is not None else torch.empty_like(gp)
+    out = out if out is not None else torch.empty_like(dy_out)
+    da = da if da is not None else torch.empty_like(dy_out)
+    check(lib().vitpe_block_tail2_bwd_pre(dtype_code(dqkv.dtype), ptr(dqkv), ptr(wqt_pk), ptr(x1), ptr(mean1), ptr(rstd1),
+                                          ptr(gamma1), ptr(dres1), ptr(dgamma1), ptr(dbeta1), K1, ptr(dy_out), ptr(gp),
+                                          ptr(w2t_pk), ptr(w1t_pk), ptr(x_mid), ptr(mean2), ptr(rstd2), ptr(gamma), ptr(du),
+                                          ptr(out), ptr(dgamma), ptr(dbeta), ptr(wpt_pk), ptr(da), M, D, HID, stream_ptr()),
+          "vitpe_block_tail2_bwd_pre")
     return out, du, da
 
 
