@@ -34,6 +34,9 @@ int vitpe_debug_tail2_census(const void* attn_out, const void* x_in, const void*
                              void* xn_out, const void* W1_packed, const float* b1, const void* W2_packed,
                              const float* b2, void* gp_out, void* h_out, void* out, float* mean_out, float* rstd_out,
                              int M, int HID, unsigned long long* census, int exp, vitpe_stream_t stream);
+/* Tile height of the big-tile bf16 GEMM behind vitpe_gemm_nt / vitpe_linear (csrc/gemm2d.hip): 0 = the host's choice per
+ * shape, 4 / 5 / 6 = (32 mt)-row tiles for every launch.  Tests and A/B measurements.                                */
+int vitpe_debug_set_gemm2d_mt(int mt);
 #ifdef __cplusplus
 }
 #endif

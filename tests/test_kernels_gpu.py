@@ -92,6 +92,40 @@ def test_gemm_nt_gelu_resid_gelubwd(K, dt):
     assert rel_err(out.float().cpu(), (u_ref - b) * ug.grad) < tol(dt)
 
 
+@pytest.mark.parametrize("mt", [0, 4, 5, 6])
+@pytest.mark.parametrize("M,N,K_", [(4200, 1024, 192), (2049, 2304, 64), (5000, 1024, 640)])
+def test_gemm_big_tile_kernel_all_epilogues(K, mt, M, N, K_):
+    """csrc/gemm2d.hip (bf16, many rows x wide weights: vitpe_gemm_nt hands these shapes to it) at every tile height, ragged
+    last row tile, one / three / ten K steps, against fp32 math on the bf16-rounded operands."""
+    from vitpe import _lib as L
+    assert L.debug_lib().vitpe_debug_set_gemm2d_mt(mt) == 0
+    try:
+        dt = "bf16"
+        a, w, b = rnd(M, K_, seed=1), rnd(N, K_, seed=2, scale=0.2), rnd(N, seed=3)
+        ref = q(a, dt) @ q(w, dt).t() + b
+        A, W = dev(a, DT[dt]), dev(w, DT[dt])
+        assert rel_err(K.gemm_nt(A, W, dev(b), epi=0).float().cpu(), ref) < tol(dt)
+        assert rel_err(K.linear(A, W, None, epi=0).float().cpu(), ref - b) < tol(dt)
+        r = rnd(M, N, seed=4)
+        out = K.gemm_nt(A, W, dev(b), epi=2, resid=dev(r, DT[dt]))
+        assert rel_err(out.float().cpu(), ref + q(r, dt)) < tol(dt)
+        h, u = K.gemm_nt(A, W, dev(b), epi=1)
+        assert rel_err(u.float().cpu(), ref) < tol(dt)
+        assert rel_err(h.float().cpu(), torch.nn.functional.gelu(ref)) < tol(dt)
+        uu = rnd(M, N, seed=5, scale=3.0)
+        ug = q(uu, dt).requires_grad_(True)
+        torch.nn.functional.gelu(ug).sum().backward()
+        out = K.gemm_nt(A, W, None, epi=4, u=dev(uu, DT[dt]))
+        assert rel_err(out.float().cpu(), (ref - b) * ug.grad) < tol(dt)
+        # row-exact check on a few rows (a tile permutation or a missing row would pass a max-norm test on random data
+        # only by luck; this pins rows at both ends of the ragged last tile)
+        o = K.gemm_nt(A, W, dev(b), epi=0).float().cpu()
+        for row in (0, 1, 127, 128, M - 2, M - 1):
+            assert rel_err(o[row], ref[row]) < tol(dt)
+    finally:
+        L.debug_lib().vitpe_debug_set_gemm2d_mt(0)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("M,N,K_", [(397, 192, 192), (1300, 768, 192), (650, 192, 768), (260, 192, 576), (33, 384, 96), (130, 192, 96)])
 def test_linear_panel_kernel_all_epilogues(K, dt, M, N, K_):
@@ -634,7 +668,7 @@ def test_wgrad_group_rejects_bad_lists(K):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("M,D", [(195, 192), (67, 96), (33, 768)])
+@pytest.mark.parametrize("M,D", [(195, 192), (67, 96), (33, 768), (4500, 768), (5, 1024), (300, 1024)])
 def test_layernorm_fwd_bwd(K, dt, M, D):
     x, g, b = rnd(M, D, seed=1, scale=2.0) + 0.3, 1 + 0.1 * rnd(D, seed=2), 0.1 * rnd(D, seed=3)
     dy, dres = rnd(M, D, seed=4), rnd(M, D, seed=5)

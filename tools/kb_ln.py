@@ -1,0 +1,21 @@
+import os, sys, torch
+sys.path.insert(0, "vit-rpe-rope_amd")
+from vitpe import kernels as K
+M, D = 12608, 768
+T = torch.bfloat16
+sets = []
+for _ in range(6):
+    x = torch.randn(M, D, device="cuda").to(T); dy = torch.randn(M, D, device="cuda").to(T); dres = torch.randn(M, D, device="cuda").to(T)
+    g = torch.ones(D, device="cuda"); _, m, r = K.layernorm_fwd(x, g, torch.zeros(D, device="cuda"))
+    sets.append((dy, x, m, r, g, torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda"), dres, torch.empty_like(x)))
+def run(i):
+    dy, x, m, r, g, dg, db, dres, out = sets[i % 6]
+    K.layernorm_bwd(dy, x, m, r, g, dg, db, dres=dres, out=out)
+for i in range(6): run(i)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for i in range(60): run(i)
+e1.record(); torch.cuda.synchronize()
+t = e0.elapsed_time(e1) / 60 * 1e3
+print(f"ln_bwd M={M} D={D}: {t:.1f} us  {4*M*D*2/t/1e6:.2f} TB/s")

@@ -9,24 +9,10 @@
 // Both are written once over T in {bf16, float} (common.h): bf16 = 16x16x32 MFMA throughput
 // mode, float = exact fp32 16x16x4 MFMA for the 1e-4 parity gate.
 #include "common.h"
+#include "gemm_nt.h"
 #include <stdlib.h>
 
 namespace vitpe {
-
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2, EPI_PATCH = 3, EPI_GELU_BWD = 4, EPI_LN_BWD = 5 };
-
-struct GemmNTArgs {
-  const void* A;      // [M,K] T
-  const void* W;      // [N,K] T
-  void* C;            // [M,N] T   (EPI_PATCH: [B*Ntok, N])
-  const float* bias;  // [N] fp32 or null
-  const void* R;      // EPI_BIAS_RESID: residual [M,N] T
-  void* U;            // EPI_BIAS_GELU: pre-activation out [M,N] T ; EPI_GELU_BWD: pre-activation in
-  const float* ape;   // EPI_PATCH: absolute PE rows [P,N] fp32 or null
-  const float* cls;   // EPI_PATCH: class token [N] fp32
-  int M, N, K;
-  int P, Ntok;        // EPI_PATCH: patches per image, tokens per image (P+1)
-};
 
 // Tile: 128 activation rows x 64 weight rows per workgroup, 128 bytes of K per stage,
 // double-buffered in LDS, register-staged global loads (issue early / write late).
@@ -720,6 +706,7 @@ extern "C" int vitpe_gemm_nt(int dtype, int epi, const void* A, const void* W, v
   if (epi == EPI_PATCH) VITPE_REQUIRE(cls != nullptr && P > 0 && Ntok == P + 1 && M % P == 0);
   if (M == 0) return 0;
   GemmNTArgs a{A, W, C, bias, R, U, ape, cls, M, N, K, P, Ntok};
+  if (gemm2d_takes(dtype, epi, M, N, K)) return gemm2d_launch(epi, a, stream);
   return dtype == 1 ? launch_gemm_nt<bf16>(epi, a, stream) : launch_gemm_nt<float>(epi, a, stream);
 }
 

@@ -62,20 +62,23 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 
 // dx[row] = (dres ? dres[row] : 0) + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
 // dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy  (per-workgroup partial sums, then fp32 atomics)
-template <typename T>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+// MAXC = 16-B chunks cached per lane, NW = waves per workgroup.  <4, 4> is the general shape; <2, 16> (D <= 1024 in bf16)
+// halves the register arrays so that 16 waves fit a CU and puts 4 rows per SIMD in flight instead of one -- a row is one
+// dependent load -> reduce -> store chain, and with 1 024 waves on the chip the d = 768 launch ran at 1.8 TB/s.
+template <typename T, int MAXC, int NW>
+__global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, const T* __restrict__ dres,
                                                      T* __restrict__ dx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int M, int D) {
   constexpr int CHN = CH<T>::n;
-  extern __shared__ __attribute__((aligned(16))) float sred[];  // [4 waves][2][D]
+  extern __shared__ __attribute__((aligned(16))) float sred[];  // [NW waves][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = D / CHN;
   const float invD = 1.0f / (float)D;
-  float ag[LN_MAXC][CHN], ab[LN_MAXC][CHN], gm[LN_MAXC][CHN];
+  float ag[MAXC][CHN], ab[MAXC][CHN], gm[MAXC][CHN];
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; ++i) {
+  for (int i = 0; i < MAXC; ++i) {
     const int ch = lane + 64 * i;
 #pragma unroll
     for (int t = 0; t < CHN; ++t) {
@@ -83,12 +86,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       gm[i][t] = (ch < nch) ? gamma[ch * CHN + t] : 0.f;
     }
   }
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+  for (int row = blockIdx.x * NW + wave; row < M; row += gridDim.x * NW) {
     const float mean = mean_in[row], rstd = rstd_in[row];
-    float xh[LN_MAXC][CHN], g[LN_MAXC][CHN];
+    float xh[MAXC][CHN], g[MAXC][CHN];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < MAXC; ++i) {
       const int ch = lane + 64 * i;
       if (ch < nch) {
         float xv[CHN], dv[CHN];
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     s1 = wave_sum(s1) * invD;
     s2 = wave_sum(s2) * invD;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < MAXC; ++i) {
       const int ch = lane + 64 * i;
       if (ch < nch) {
         float o[CHN];
@@ -124,22 +127,47 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       }
     }
   }
-  // cross-wave reduction, fixed order
+  // cross-wave reduction, fixed order; NS = min(NW, 8) slots of [2][D] (16 waves fold pairwise first: 16 slots of d = 768
+  // would be 96 KB of dynamic LDS)
+  constexpr int NS = NW < 8 ? NW : 8;
+  auto park = [&](int slot) {
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; ++i) {
-    const int ch = lane + 64 * i;
-    if (ch < nch) {
+    for (int i = 0; i < MAXC; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
 #pragma unroll
-      for (int t = 0; t < CHN; ++t) {
-        sred[(wave * 2 + 0) * D + ch * CHN + t] = ag[i][t];
-        sred[(wave * 2 + 1) * D + ch * CHN + t] = ab[i][t];
+        for (int t = 0; t < CHN; ++t) {
+          sred[(slot * 2 + 0) * D + ch * CHN + t] = ag[i][t];
+          sred[(slot * 2 + 1) * D + ch * CHN + t] = ab[i][t];
+        }
       }
     }
+  };
+  if (NW > NS) {
+    if (wave >= NS) park(wave - NS);
+    __syncthreads();
+    if (wave < NS) {
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+#pragma unroll
+          for (int t = 0; t < CHN; ++t) {
+            ag[i][t] += sred[(wave * 2 + 0) * D + ch * CHN + t];
+            ab[i][t] += sred[(wave * 2 + 1) * D + ch * CHN + t];
+          }
+        }
+      }
+    }
+    __syncthreads();
   }
+  if (wave < NS) park(wave);
   __syncthreads();
   // 2*D atomics per workgroup onto 2*D addresses: <= 256 workgroups, a few microseconds
-  for (int i = threadIdx.x; i < 2 * D; i += 256) {
-    const float s = sred[i] + sred[2 * D + i] + sred[4 * D + i] + sred[6 * D + i];
+  for (int i = threadIdx.x; i < 2 * D; i += NW * 64) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NS; ++w) s += sred[2 * D * w + i];
     atomicAdd((i < D ? dgamma + i : dbeta + (i - D)), s);
   }
 }
@@ -343,11 +371,16 @@ extern "C" int vitpe_layernorm_bwd(int dtype, const void* dy, const void* x, con
                        mean, rstd, gamma, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, M, D);
     VITPE_CHECK_LAUNCH();
   }
-  if (dtype == 1)
-    hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3(blocks), dim3(256), shm, stream, (const bf16*)dy, (const bf16*)x,
+  if (dtype == 1 && D <= 1024) {
+    const int blocks16 = min((M + 15) / 16, 256);
+    hipLaunchKernelGGL((ln_bwd_kernel<bf16, 2, 16>), dim3(blocks16), dim3(1024), (size_t)8 * 2 * D * sizeof(float), stream,
+                       (const bf16*)dy, (const bf16*)x, mean, rstd, gamma, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, M, D);
+  } else if (dtype == 1) {
+    hipLaunchKernelGGL((ln_bwd_kernel<bf16, LN_MAXC, 4>), dim3(blocks), dim3(256), shm, stream, (const bf16*)dy, (const bf16*)x,
                        mean, rstd, gamma, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, M, D);
-  else
-    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(blocks), dim3(256), shm, stream, (const float*)dy,
+  } else {
+    hipLaunchKernelGGL((ln_bwd_kernel<float, LN_MAXC, 4>), dim3(blocks), dim3(256), shm, stream, (const float*)dy,
                        (const float*)x, mean, rstd, gamma, (const float*)dres, (float*)dx, dgamma, dbeta, M, D);
+  }
   VITPE_CHECK_LAUNCH();
 }
