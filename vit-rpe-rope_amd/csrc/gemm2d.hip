@@ -16,9 +16,11 @@
 // three buffers: a K step is ~1.3 K cycles of MFMA work, less than the DMA's latency), compute kt.
 //
 // The MFMA orientation is swapped (A operand = weight rows, B operand = activation rows): a lane's accumulator holds 4
-// consecutive output columns of one row.  Epilogue: each wave parks 32 rows x 64 columns of fp32 accumulators in its own
-// slice of the idle stage buffers (no workgroup barrier), reads them back as 8-column pieces -- 8 lanes cover a row's 128
-// contiguous output bytes -- and applies bias / residual / GELU with 16-byte loads and stores.
+// consecutive output columns of one row.  Epilogue, in registers: one v_permlane16_swap per dword between lane groups g and
+// g ^ 1 gives every lane 8 consecutive columns (fp32), bias / residual / GELU are applied on those and the row leaves as
+// 16-byte pieces (64 contiguous bytes per 4 lanes).  The kernel is persistent (one workgroup per CU walks its tiles): the
+// next tile's first stages are issued before the epilogue, and the epilogue's stores stay in flight under the next tile's
+// first K steps (counted waits, see sync()).
 #include "common.h"
 #include "gemm_nt.h"
 #include <stdlib.h>
@@ -35,8 +37,7 @@ __global__ __launch_bounds__(512) void gemm2d_kernel(GemmNTArgs a) {
   constexpr int AI = (AG + 7) / 8, WI = WG_ / 8;      // instructions per wave and stage
   constexpr int NBUF = (3 * STAGE <= 160 * 1024) ? 3 : 2;
   constexpr int AHEAD = NBUF - 1;                     // stages in flight
-  constexpr int EP_LD = 68;                           // fp32 row stride of a parked 16 x 64 slice
-  static_assert(AI + WI < 16 && 8 * 16 * EP_LD * 4 <= STAGE, "wait counts fit 4 bits; parked slices fit one stage buffer");
+  static_assert(AI + WI < 16, "stage wait counts fit 4 bits");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NBUF * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
@@ -161,8 +162,8 @@ __global__ __launch_bounds__(512) void gemm2d_kernel(GemmNTArgs a) {
       if (i < nk) stage(i, i);
   };
 
-  // ---- persistent over tiles: the next tile's first stages are issued BEFORE this tile's epilogue (whose scratch is the
-  // last stage buffer), so the epilogue's LDS passes, arithmetic and stores run under the next tile's load latency.
+  // ---- persistent over tiles: the next tile's first stages are issued BEFORE this tile's epilogue, so the epilogue's
+  // arithmetic and stores run under the next tile's load latency.
   int m0, n0;
   tile_of(blockIdx.x, m0, n0);
   sources(m0, n0);
@@ -175,25 +176,25 @@ __global__ __launch_bounds__(512) void gemm2d_kernel(GemmNTArgs a) {
     sync(0);
     if (AHEAD < nk) stage(AHEAD, AHEAD);
     // epilogue operands that do not depend on the product: issued now, used after the main loop
-    float* ep = reinterpret_cast<float*>(smem + (NBUF - 1) * STAGE) + wave * (16 * EP_LD);
+    // After the register exchange below a lane owns, for each of the two tile pairs p, 8 consecutive columns of row c:
+    // columns 32 p + 16 (g & 1) + 8 (g >> 1) .. + 7 of the wave's 64.
     T* __restrict__ C = reinterpret_cast<T*>(a.C);
-    const int er = lane >> 3, n8 = (lane & 7) * 8;    // this lane's row (of 8 per iteration) and 8-column piece
-    const int gn = n0 + wn * 64 + n8;
-    const int row0 = m0 + wm * (16 * MT) + er;
+    const int gn = n0 + wn * 64 + 16 * (g & 1) + 8 * (g >> 1);
+    const int row0 = m0 + wm * (16 * MT) + c;
     constexpr bool HAS_IN = EPI == EPI_BIAS_RESID || EPI == EPI_GELU_BWD;    // an [M,N] input of the epilogue (R or U)
     const T* __restrict__ IN = reinterpret_cast<const T*>(EPI == EPI_BIAS_RESID ? a.R : a.U);
-    float bv[8];
+    float bv[2][8];
     Chunk16 in_cur[2], in_nxt[2];
     auto load_in = [&](int mt, Chunk16* dst) {        // one pass AHEAD of its use: a wait for it never waits for a younger store
+      int gm = row0 + 16 * mt;
+      gm = gm < M ? gm : M - 1;
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        int gm = row0 + 16 * mt + 8 * it;
-        gm = gm < M ? gm : M - 1;
-        dst[it] = *reinterpret_cast<const Chunk16*>(IN + (size_t)gm * N + gn);
-      }
+      for (int p = 0; p < 2; ++p) dst[p] = *reinterpret_cast<const Chunk16*>(IN + (size_t)gm * N + gn + 32 * p);
     };
 #pragma unroll
-    for (int i = 0; i < 8; ++i) bv[i] = (EPI != EPI_GELU_BWD && a.bias != nullptr) ? a.bias[gn + i] : 0.f;
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bv[p][i] = (EPI != EPI_GELU_BWD && a.bias != nullptr) ? a.bias[gn + 32 * p + i] : 0.f;
     if (HAS_IN) load_in(0, in_cur);
     rd(0, 0, fwP, faP);
     rd(0, 1, fwQ, faQ);
@@ -218,14 +219,16 @@ __global__ __launch_bounds__(512) void gemm2d_kernel(GemmNTArgs a) {
     asm volatile("s_barrier" ::: "memory");           // every fragment read of this tile is done: all stage buffers are free
 
     const int cm0 = m0;
-    // ---- epilogue: 16 rows x 64 columns of fp32 per wave and pass through the wave's own slice of the last stage buffer.
+    // ---- epilogue.
     // Two copies behind one wave-uniform branch: the common one has NO per-row conditions (a divergent `if` around a load
     // or store makes the compiler wait vmcnt(0) at the join -- that would drain the next tile's DMA and this tile's
     // stores at every pass); the ragged one (the wave's rows cross M) masks rows and ends with vmcnt(0).
     // the bias values and the first pass's input rows have been in flight since the tile's start; retire them BEFORE the
     // next tile's DMA is issued (behind it, the compiler's wait for them would be a wait for the DMA as well)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(bv[i]));
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(bv[p][i]));
     if (HAS_IN) asm volatile("" : "+v"(in_cur[0]), "+v"(in_cur[1]));
     if (id + (int)gridDim.x < total) {
       tile_of(id + gridDim.x, m0, n0);
@@ -236,25 +239,24 @@ __global__ __launch_bounds__(512) void gemm2d_kernel(GemmNTArgs a) {
       constexpr bool RAGGED = decltype(ragged_tag)::value;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4*>(ep + c * EP_LD + 16 * nt + 4 * g) = acc[nt][mt];
-        asm volatile("" ::: "memory");                // (in-order LDS pipe: the wave's reads below see all of its lanes' writes)
         if (HAS_IN && mt + 1 < MT) load_in(mt + 1, in_nxt);
+        const int gm = row0 + 16 * mt;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int r = 8 * it + er;
-          const int gm = row0 + 16 * mt + 8 * it;
+        for (int p = 0; p < 2; ++p) {
+          // lane (c, g) holds columns 16 nt + 4 g .. + 3 of row c for nt = 2p, 2p + 1; one v_permlane16_swap per dword
+          // hands the odd lane group's tile-2p values to the even group and the even group's tile-(2p+1) values to the odd
           float v[8];
-          {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + n8);
-            const f32x4 y = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + n8 + 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { v[i] = x[i] + bv[i]; v[4 + i] = y[i] + bv[4 + i]; }
+          for (int j = 0; j < 4; ++j) {
+            const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * p][mt][j]), __float_as_uint(acc[2 * p + 1][mt][j]),
+                                                            false, false);
+            v[j] = __uint_as_float(r[0]) + bv[p][j];
+            v[4 + j] = __uint_as_float(r[1]) + bv[p][4 + j];
           }
-          const size_t off = (size_t)gm * N + gn;
+          const size_t off = (size_t)gm * N + gn + 32 * p;
           if (EPI == EPI_BIAS_RESID) {
             float rv[8];
-            chunk_to_f32<T>(in_cur[it], rv);
+            chunk_to_f32<T>(in_cur[p], rv);
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] += rv[i];
           }
@@ -265,13 +267,12 @@ __global__ __launch_bounds__(512) void gemm2d_kernel(GemmNTArgs a) {
           }
           if (EPI == EPI_GELU_BWD) {
             float uv[8];
-            chunk_to_f32<T>(in_cur[it], uv);
+            chunk_to_f32<T>(in_cur[p], uv);
             gelu_erf_grad_mul_x8(v, uv);
           }
           const Chunk16 co = f32_to_chunk<T>(v);
           if (!RAGGED || gm < M) *reinterpret_cast<Chunk16*>(C + off) = co;
         }
-        asm volatile("" ::: "memory");
         if (HAS_IN) { in_cur[0] = in_nxt[0]; in_cur[1] = in_nxt[1]; }
       }
     };
