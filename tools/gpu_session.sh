@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call = tests + bench + kernel-trace profile.  A step that is KILLED (timeout / signal) ends the session:
 # nothing further touches the GPU after a hang; ordinary failures (assertions) let the later steps run.
-#   tools/gpu_session.sh <tag> [steps...]      steps: tests bench prof pmc imnet sweep   (default: tests bench prof)
+#   tools/gpu_session.sh <tag> [steps...]      steps: tests testsall bench prof pmc imnet imnetprof sweep   (default: tests bench prof)
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 tag=${1:-s}; shift
@@ -33,6 +33,10 @@ for s in $steps; do
          done
          python3 tools/summarize_pmc.py $out $tag ${PMC_ARGS} ;;
     imnet) run imnet 400 python bench.py --config imnet --steps 20 --warmup 5 --no-cpu-baseline > $out/${tag}_imnet.json 2> $out/${tag}_imnet.err; cat $out/${tag}_imnet.json ;;
+    imnetprof) rm -rf $out/${tag}_imnet_prof
+          run imnetprof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_imnet_prof -o step -- python3 bench.py --config imnet --steps 15 --warmup 5 --no-cpu-baseline --no-kernel-probes > /dev/null 2> $out/${tag}_imnet_prof.err
+          f=$(find $out/${tag}_imnet_prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $out/${tag}_imnet_step_kernel_stats.csv && python3 tools/short_stats.py $out/${tag}_imnet_step_kernel_stats.csv | head -24
+          find $out/${tag}_imnet_prof -name '*kernel_trace.csv' -size +8M -delete ;;
     sweep) run sweep 900 bash tools/bench_sweep.sh $out/${tag}_sweep.jsonl; cat $out/${tag}_sweep.jsonl | cut -c1-200 ;;
     *) echo "unknown step $s" ;;
   esac

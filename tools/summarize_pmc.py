@@ -28,7 +28,8 @@ PROBES = {
     "attn_fwd": ["attn_fwd_kernel"],
     "attn_bwd": ["attn_bwd"],
     "block_tail_fwd": ["block_tail2_fwd_kernel"],
-    "block_tail_bwd": ["block_tail2_bwd_kernel"],
+    "block_tail_bwd": ["block_tail2_bwd_kernel<false>"],
+    "block_tail_bwd_pre": ["block_tail2_bwd_kernel<true>"],       # with the upper block's qkv data gradient + LN1 backward
     "wgrad_group": ["wgrad_group_kernel"],
     "dgrad_qkv_ln1_bwd": ["ln_bwd2_kernel"],
     "head_step": ["head_step_kernel"],
@@ -40,7 +41,7 @@ PROBES = {
 FALLBACK = {
     "dgrad_qkv_ln1_bwd": [["gemm_panel_kernel"]],
     "block_tail_fwd": [["mlp_fwd_kernelIDF16bLi0E"], ["mlp_fwd_kernel<", "0, true"]],
-    "block_tail_bwd": [["vitpe::mlp_fwd_kernel<"], ["mlp_fwd_kernelIDF16bLi1E"]],
+    "block_tail_bwd": [["block_tail2_bwd_kernel"], ["vitpe::mlp_fwd_kernel<"], ["mlp_fwd_kernelIDF16bLi1E"]],
 }
 
 

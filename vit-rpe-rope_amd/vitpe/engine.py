@@ -819,6 +819,16 @@ class TrainEngine:
                                " (gelu'+dgrad fc2/fc1+LN2 bwd+residual+dgrad proj)",
                                fns=[tail_b(l) for l in range(self.Lyr)], flop=tail_flop,
                                bytes=self._tail_bytes(fwd=False)))
+            if self.tail2 and self.tail2_bwd and self.fuse_lnbwd and self.Lyr > 1:
+                def tail_bp(l):
+                    blk, a = mdl.blocks[l], self.act[l]
+                    return lambda: self._block_tail_bwd(l, blk, a, pre=True)
+                # what the step runs between blocks: block l + 1's qkv data gradient + LayerNorm1 backward, then block l's
+                # tail backward; dy is written once (the weight gradients read it) and not read back
+                probes.append(dict(name="block_tail_bwd_pre",
+                                   kernel="block_tail2_bwd_kernel<PRE> (dgrad qkv + LN1 bwd of the block above, then the tail backward)",
+                                   fns=[tail_bp(l) for l in range(self.Lyr - 1)], flop=tail_flop + 2 * M * D * 3 * D,
+                                   bytes=self._tail_bytes(fwd=False) + (3 * M * D + 2 * M * D) * es))
             if self.lnbwd2:
                 def dg(l):
                     blk, a = mdl.blocks[l], self.act[l]
