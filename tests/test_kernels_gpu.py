@@ -589,6 +589,34 @@ def test_wgrad_group_many_problems_one_launch(K, dt):
         assert rel_err(dw.cpu(), 2 * rw) < tol(dt)
 
 
+@pytest.mark.parametrize("M", [64, 640, 65 * 64])
+def test_wgrad_group_full_blocks_and_stages(K, M):
+    """bf16 with every M a multiple of 64 and every N, K a multiple of 192 (the shapes of the bench path): work runs crossing
+    block and problem boundaries, one- and two-stage problems, bias on and off, accumulation over launches; per-row check on
+    one problem."""
+    shapes = [(M, 576, 192, True), (M, 192, 192, True), (2 * M, 768, 192, True), (M, 192, 768, False), (64, 192, 384, True),
+              (128, 384, 192, True)]
+    probs, refs = [], []
+    for i, (M_, N, K_, bias) in enumerate(shapes):
+        dy, x = rnd(M_, N, seed=110 + i), rnd(M_, K_, seed=140 + i)
+        dw = torch.zeros(N, K_, device="cuda")
+        db = torch.zeros(N, device="cuda") if bias else None
+        probs.append((dev(dy, torch.bfloat16), dev(x, torch.bfloat16), dw, db))
+        refs.append((q(dy, "bf16").t() @ q(x, "bf16"), q(dy, "bf16").sum(0)))
+    grp = K.WgradGroup(probs)
+    grp.launch()
+    for (dy, x, dw, db), (rw, rb) in zip(probs, refs):
+        assert rel_err(dw.cpu(), rw) < BF16_TOL, tuple(dw.shape)
+        if db is not None:
+            assert rel_err(db.cpu(), rb) < BF16_TOL, tuple(dw.shape)
+    d0, r0 = probs[0][2].cpu(), refs[0][0]
+    for row in (0, 47, 48, 191, 192, 575):     # wave-tile and block edges: a misplaced tile shows in its own rows
+        assert rel_err(d0[row], r0[row]) < BF16_TOL, row
+    grp.launch()   # accumulates
+    for (dy, x, dw, db), (rw, rb) in zip(probs, refs):
+        assert rel_err(dw.cpu(), 2 * rw) < BF16_TOL
+
+
 def test_wgrad_group_large_balanced_run(K):
     """bench-like sizes (many stages per block, work runs crossing block and problem boundaries)"""
     M = 65 * 96
