@@ -617,6 +617,32 @@ def test_wgrad_group_full_blocks_and_stages(K, M):
         assert rel_err(dw.cpu(), 2 * rw) < BF16_TOL
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_wgrad_group_window_mode_many_blocks(K, dt):
+    """A list of more than two chip-fulls of 192 x 192 blocks (the ViT-B/16 weight gradients: 1 152 per launch) is run in
+    windows of whole blocks, the last partial window in row ranges: every problem against dY^T X, ragged edges included."""
+    shapes = [(192, 960, 960, True)] * 10 + [(200, 960, 904, False)] * 8 + [(64, 1152, 768, True)] * 4 + [(330, 200, 392, True)] * 2
+    probs, refs = [], []
+    for i, (M, N, K_, bias) in enumerate(shapes):
+        dy, x = rnd(M, N, seed=210 + i), rnd(M, K_, seed=250 + i)
+        dw = torch.zeros(N, K_, device="cuda")
+        db = torch.zeros(N, device="cuda") if bias else None
+        probs.append((dev(dy, DT[dt]), dev(x, DT[dt]), dw, db))
+        refs.append((q(dy, dt).t() @ q(x, dt), q(dy, dt).sum(0)))
+    assert sum(-(-N // 192) * -(-K_ // 192) for _, N, K_, _ in shapes) >= 2 * 256
+    grp = K.WgradGroup(probs)
+    grp.launch()
+    for (dy, x, dw, db), (rw, rb) in zip(probs, refs):
+        assert rel_err(dw.cpu(), rw) < tol(dt), tuple(dw.shape)
+        if db is not None:
+            assert rel_err(db.cpu(), rb) < tol(dt), tuple(dw.shape)
+    for row in (0, 191, 192, 959):
+        assert rel_err(probs[0][2][row].cpu(), refs[0][0][row]) < tol(dt), row
+    grp.launch()   # accumulates
+    for (dy, x, dw, db), (rw, rb) in zip(probs, refs):
+        assert rel_err(dw.cpu(), 2 * rw) < tol(dt)
+
+
 def test_wgrad_group_large_balanced_run(K):
     """bench-like sizes (many stages per block, work runs crossing block and problem boundaries)"""
     M = 65 * 96

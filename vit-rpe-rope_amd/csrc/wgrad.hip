@@ -49,8 +49,9 @@ struct WgProb {
 constexpr int WG_TABLE = 512;
 struct WgArgs {
   int nprob, total_units, units_per_wg;
-  int use_table;   // 1: workgroup i runs table[i] = (problem << 11 | block << 5 | row range), 0xFFFF = idle
-  int nranges;     // row ranges per block in table mode
+  int use_table;   // 1: workgroup i runs table[i] = (problem << 11 | block << 5 | row range), 0xFFFF = idle; 2: window mode
+  int nranges;     // row ranges per block in table mode (window mode: of the blocks of the last, partial window)
+  int full_rounds, total_blocks;   // window mode (use_table == 2): whole windows of gridDim.x blocks; blocks in the list
   unsigned long long* census;   // CENSUS build only (vitpe_debug_wgrad_census): s_memtime stamps
   WgProb p[WG_MAXPROB];
   unsigned short table[WG_TABLE];
@@ -244,8 +245,76 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
   // Table mode: one (block, row range) per workgroup, placed by the host so that the blocks of one problem that
   // share an operand over the same rows (e.g. the four n-blocks of fc1 all read xn2) run at the same time on
   // the SAME XCD (workgroup id % 8) -- the shared rows are fetched from HBM once and hit in that XCD's L2.
+  bool first_run = true;
+  auto run = [&](int u0, int uend) {
+    if (!first_run) __syncthreads();   // the previous run's last stage may still be read by a slower wave
+    first_run = false;
+  Cur cur, nxt;
+    decode(u0, cur);
+    gload(cur);
+    clear();
+    // CENSUS: lane 0 of every wave stamps the shader clock of the first 24 stages: 0 stage stored, 2 next loads
+    // issued, 1 barrier passed, 3 MFMAs done
+    auto stamp = [&](int u, int slot) {
+      if (CENSUS && lane == 0 && u - u0 < WG_CENSUS_STAGES)
+        a.census[(((size_t)blockIdx.x * 12 + wave) * WG_CENSUS_STAGES + (u - u0)) * WG_CENSUS_SLOTS + slot] = __builtin_amdgcn_s_memtime();
+    };
+    for (int u = u0; u < uend; ++u) {
+      const int buf = (u - u0) & 1;
+      sstore(buf);
+      stamp(u, 0);
+      nxt = cur;
+      bool flush_now = (u + 1 == uend);
+      if (u + 1 < uend) {
+        if (cur.stage + 1 < cur.stages) nxt.stage = cur.stage + 1;
+        else { decode(u + 1, nxt); flush_now = true; }
+        gload(nxt);  // in flight under this stage's MFMAs
+      }
+      stamp(u, 2);
+      __syncthreads();
+      stamp(u, 1);
+      const bool bias = (cur.dbias != nullptr) && cur.k0 == 0 && wk == 0;
+      compute(buf, bias || (LNX && cur.xop == 1));   // LayerNorm operand: every wave needs the column sums of dY (beta term)
+      stamp(u, 3);
+      if (flush_now) flush(cur, bias);
+      cur = nxt;
+    }
+  };
+
+  // Window mode (big lists: at least two windows of gridDim.x blocks): every workgroup takes WHOLE blocks, one per round;
+  // round r runs the gridDim.x consecutive blocks of window r at the same time and gives each XCD (workgroup id % 8) a
+  // contiguous eighth of them -- with the n-blocks of a problem adjacent, the workgroups of an XCD then walk the same token
+  // rows of the same dY / X column blocks in step and the second reader is served by that XCD's L2.  (Stream-K hands
+  // every CU a contiguous run of units instead: the blocks alive at one time are far apart in the list, nothing is shared
+  // and every stage of every block comes through the fabric -- 11.4 GB per launch on the ViT-B/16 list for 1.9 GB of
+  // operands.)  One flush per block; the last, partial window is cut into row ranges so that it still fills the chip.
+  if (a.use_table == 2) {
+    const int G = gridDim.x, idx = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    for (int r = 0; r <= a.full_rounds; ++r) {
+      int gb, rng = 0, R = 1;
+      if (r < a.full_rounds) {
+        gb = r * G + idx;
+      } else {
+        R = a.nranges;
+        gb = a.full_rounds * G + idx / R;
+        rng = idx % R;
+      }
+      if (gb >= a.total_blocks) continue;
+      int pi = 0, b0 = 0;
+      for (int i = 0; i < a.nprob; ++i) {
+        const int nb = a.p[i].nbn * ((a.p[i].K + WG_BLK - 1) / WG_BLK);
+        if (gb >= b0 + nb) { b0 += nb; pi = i + 1; } else break;
+      }
+      const WgProb& P = a.p[pi];
+      const int spr = (P.stages + R - 1) / R;
+      const int ub = P.unit0 + (gb - b0) * P.stages;
+      const int u0 = ub + min(P.stages, rng * spr), uend = ub + min(P.stages, (rng + 1) * spr);
+      if (u0 < uend) run(u0, uend);
+    }
+    return;
+  }
   int u0, uend;
-  if (a.use_table) {
+  if (a.use_table == 1) {
     const unsigned ent = a.table[blockIdx.x];
     if (ent == 0xFFFFu) return;
     const WgProb& P = a.p[ent >> 11];
@@ -258,36 +327,7 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
     uend = min(a.total_units, u0 + a.units_per_wg);
   }
   if (u0 >= uend) return;
-  Cur cur, nxt;
-  decode(u0, cur);
-  gload(cur);
-  clear();
-  // CENSUS: lane 0 of every wave stamps the shader clock of the first 24 stages: 0 stage stored, 2 next loads
-  // issued, 1 barrier passed, 3 MFMAs done
-  auto stamp = [&](int u, int slot) {
-    if (CENSUS && lane == 0 && u - u0 < WG_CENSUS_STAGES)
-      a.census[(((size_t)blockIdx.x * 12 + wave) * WG_CENSUS_STAGES + (u - u0)) * WG_CENSUS_SLOTS + slot] = __builtin_amdgcn_s_memtime();
-  };
-  for (int u = u0; u < uend; ++u) {
-    const int buf = (u - u0) & 1;
-    sstore(buf);
-    stamp(u, 0);
-    nxt = cur;
-    bool flush_now = (u + 1 == uend);
-    if (u + 1 < uend) {
-      if (cur.stage + 1 < cur.stages) nxt.stage = cur.stage + 1;
-      else { decode(u + 1, nxt); flush_now = true; }
-      gload(nxt);  // in flight under this stage's MFMAs
-    }
-    stamp(u, 2);
-    __syncthreads();
-    stamp(u, 1);
-    const bool bias = (cur.dbias != nullptr) && cur.k0 == 0 && wk == 0;
-    compute(buf, bias || (LNX && cur.xop == 1));   // LayerNorm operand: every wave needs the column sums of dY (beta term)
-    stamp(u, 3);
-    if (flush_now) flush(cur, bias);
-    cur = nxt;
-  }
+  run(u0, uend);
 }
 
 }  // namespace vitpe
@@ -401,6 +441,20 @@ static int wgrad_group_launch(int dtype, const void* problems, int nprob, unsign
       a.nranges = R;
       grid = mx * 8;
     }
+  }
+  static const bool windows_ok = !(getenv("VITPE_WGRAD_WINDOWS") && getenv("VITPE_WGRAD_WINDOWS")[0] == '0');
+  const int G = ncu & ~7;
+  if (!a.use_table && windows_ok && G >= 8 && total_blocks >= 2 * G && r_force == 0 && table_ok) {
+    a.use_table = 2;
+    a.total_blocks = total_blocks;
+    a.full_rounds = total_blocks / G;
+    const int rem = total_blocks - a.full_rounds * G;
+    int Rl = rem > 0 ? G / rem : 1;
+    if (Rl > min_stages / 4) Rl = min_stages / 4;
+    if (Rl > 31) Rl = 31;
+    if (Rl < 1) Rl = 1;
+    a.nranges = Rl;
+    grid = G;
   }
   if (!a.use_table) {
     const int wgs = units < ncu ? units : ncu;
