@@ -125,6 +125,12 @@ __global__ __launch_bounds__(64 * NW) void attn_core_fwd_kernel(AttnArgs a) {
     for (int cs = 0; cs < C::HC; ++cs)
       bq[cs] = ld_rot_frag<HD, ROPE>(qg + (size_t)il * 3 * Dr, 32 * cs + 8 * g, cosb + (size_t)(tok - 1) * (HD / 2),
                                      sinb + (size_t)(tok - 1) * (HD / 2), il >= 1, a.scale * LOG2E);
+    // the rotated query fragments are FINISHED here (pinned), and the K fragment reads below stay below: unpinned, the
+    // compiler hoists all 26 LDS reads above the query's global loads, carries the rotation's fp32 temporaries and spills 25
+    // registers at the 128-VGPR cap of a 13-wave workgroup -- 60 MB of scratch writes per launch at the ViT-B/16 geometry
+#pragma unroll
+    for (int cs = 0; cs < C::HC; ++cs) pin_frag(bq[cs]);
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 s[MT];
     const float m = logits_T<T, C, KM>(a, kt, bq, s_tab, s_coef, 0, it, lane, s);
     float l = 0.f;

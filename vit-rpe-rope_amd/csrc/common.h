@@ -52,6 +52,14 @@ VITPE_DEV void mma(const Frag<float>& a, const Frag<float>& b, f32x4& c) {
   for (int t = 0; t < 8; ++t) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[t], b.v[t], c, 0, 0, 0);
 }
 
+// the fragment's value is FINAL here: keeps the compiler from sinking the conversions that produce it past later code
+// (and carrying the fp32 sources instead -- DESIGN.md, round-2 log)
+VITPE_DEV void pin_frag(Frag<bf16>& f) { asm volatile("" : "+v"(f.v)); }
+VITPE_DEV void pin_frag(Frag<float>& f) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) asm volatile("" : "+v"(f.v[t]));
+}
+
 template <typename T> VITPE_DEV Frag<T> zero_frag();
 template <> VITPE_DEV Frag<bf16> zero_frag<bf16>() {
   Frag<bf16> f;
