@@ -643,6 +643,23 @@ def test_wgrad_group_window_mode_many_blocks(K, dt):
         assert rel_err(dw.cpu(), 2 * rw) < tol(dt)
 
 
+def test_wgrad_group_range_major_windows_model_sized_list(K):
+    """A list the size of the CIFAR model's (24 nn.Linear problems, 72 blocks of 192 x 192) with enough rows for seven row
+    ranges per block: 504 (range, block) pairs dealt range-major over two rounds of the chip, a partial flush per pair."""
+    M = 64 * 29 + 17
+    probs, refs = [], []
+    for i, (N, K_) in enumerate([(576, 192), (192, 192), (768, 192), (192, 768)] * 6):
+        dy, x = rnd(M, N, seed=310 + i), rnd(M, K_, seed=350 + i)
+        dw, db = torch.zeros(N, K_, device="cuda"), torch.zeros(N, device="cuda")
+        probs.append((dev(dy, torch.bfloat16), dev(x, torch.bfloat16), dw, db))
+        refs.append((q(dy, "bf16").t() @ q(x, "bf16"), q(dy, "bf16").sum(0)))
+    K.wgrad_group(probs)
+    for (dy, x, dw, db), (rw, rb) in zip(probs, refs):
+        assert rel_err(dw.cpu(), rw) < BF16_TOL and rel_err(db.cpu(), rb) < BF16_TOL, tuple(dw.shape)
+    for row in (0, 191, 192, 575):
+        assert rel_err(probs[0][2][row].cpu(), refs[0][0][row]) < BF16_TOL, row
+
+
 def test_wgrad_group_large_balanced_run(K):
     """bench-like sizes (many stages per block, work runs crossing block and problem boundaries)"""
     M = 65 * 96
