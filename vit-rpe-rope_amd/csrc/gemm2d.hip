@@ -132,7 +132,8 @@ __global__ __launch_bounds__(512) void gemm2d_kernel(GemmNTArgs a) {
   // (A raw s_barrier: __syncthreads() would drain the DMA in flight.)  Step 0 waits for everything: the previous tile's
   // stores are in the same counter.
 #define VITPE_WAITVM(n) __builtin_amdgcn_s_waitcnt(0x0070 | ((n) & 15) | (((n) >> 4) << 14))   /* vmcnt(n) lgkmcnt(0) */
-  // vmcnt counts loads, LDS-DMA pieces and stores alike and retires them in issue order.  A tile's first stages are issued
+  // vmcnt counts loads, LDS-DMA pieces and stores alike and retires them in issue order (MI355X_MICROARCH.md, `s_waitcnt
+  // vmcnt(N)`: "all but the wave's N youngest vector-memory operations are done"; flat_* excepted, none here).  A tile's first stages are issued
   // BEFORE the previous tile's epilogue, so at steps 0 and 1 (AHEAD == 2; step 0 with two buffers) the wait leaves that
   // epilogue's EP_OPS loads / stores outstanding as well: the stores drain under the first K steps instead of stalling the
   // tile start.  ep_pending is EP_OPS, or 0 for the first tile and after a ragged tile (whose waves skip instructions for
