@@ -36,6 +36,15 @@ PROBES = {
     "patch_embed": ["patch_embed_kernel"],
     "adamw": ["adamw_kernel"],
     "refresh_shadows": ["refresh_shadows_kernel"],
+    # ViT-B/16 geometry (bench.py --config imnet): the big-tile GEMM by epilogue, the attention core, stand-alone LayerNorm
+    "gemm2d_bias": ["gemm2d_kernel<5, 0>"],
+    "gemm2d_bias_gelu": ["gemm2d_kernel<5, 1>"],
+    "gemm2d_bias_resid": ["gemm2d_kernel<5, 2>"],
+    "gemm2d_gelu_bwd": ["gemm2d_kernel<5, 4>"],
+    "attn_core_fwd": ["attn_core_fwd_kernel"],
+    "attn_core_bwd": ["attn_core_bwd_kernel"],
+    "layernorm_fwd": ["ln_fwd_kernel"],
+    "layernorm_bwd": ["ln_bwd_kernel"],
 }
 # first-generation block-tail kernels (when the second generation does not run): mangled vs demangled spelling
 FALLBACK = {
