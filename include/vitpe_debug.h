@@ -23,6 +23,10 @@ int vitpe_debug_wgrad_census(int dtype, const vitpe_wgrad_problem* problems, int
  * 4 k projected, 5 q projected, 6 end                                                                              */
 int vitpe_debug_attn_census(const void* xn, const void* wqkv, void* out, const float* cos, const float* sin,
                             int B, unsigned long long* census, vitpe_stream_t stream);
+/* the same for the wide forward (csrc/attn32.hip; wqkv_wide = vitpe_pack_qkv_weights_wide): slots 0 start, 1 staged,
+ * 2 barrier passed, 3 65th token projected + exchanged, 4 v, 5 k, 6 q, 7 end                                       */
+int vitpe_debug_attn32_census(const void* xn, const void* wqkv_wide, void* out, const float* cos, const float* sin,
+                              int B, unsigned long long* census, vitpe_stream_t stream);
 /* phase census of the second-generation block tail (training instantiation with stamps; bf16, D = 192):
  * census[(workgroup * 9 + wave) * 16 + slot] = s_memtime at 0 start, 1 first slab landed, 2 proj product done,
  * 3 LayerNorm2 epilogue done, 4 period-0 barrier passed, 5 period 0 done, 6 periods 1.. done, 7 last barrier passed,

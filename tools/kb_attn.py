@@ -33,7 +33,9 @@ def main():
     r = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(T)  # noqa: E731
     xs, outs, xns, douts, dqkvs = ([r(B, N, D) for _ in range(L)] for _ in range(5))
     dqkvs = [torch.empty(B, N, 3 * D, device=dev, dtype=T) for _ in range(L)]
-    ws = [K.pack_qkv_weights(torch.randn(3 * D, D, device=dev) * 0.1, T, H) for _ in range(L)]
+    Ws = [torch.randn(3 * D, D, device=dev) * 0.1 for _ in range(L)]
+    ws = [K.pack_qkv_weights(w_, T, H) for w_ in Ws]
+    wws = [K.pack_qkv_weights_wide(w_, T, H) for w_ in Ws]
     gam, bet = torch.ones(D, device=dev), torch.zeros(D, device=dev)
     stats = [K.layernorm_fwd(x, gam, bet, stats_only=True)[1:] for x in xs]
     inv = 1.0 / (100.0 ** (torch.arange(0, 8, dtype=torch.float) / 8))
@@ -57,10 +59,14 @@ def main():
         f_ln = [(lambda l=l: K.fused_attention_fwd(xs[l], ws[l], H, pe, out=outs[l], ln=(gam, bet) + tuple(stats[l]),
                                                    xn_out=xns[l])) for l in range(L)]
         f_pl = [(lambda l=l: K.fused_attention_fwd(xns[l], ws[l], H, pe, out=outs[l])) for l in range(L)]
+        f_wl = [(lambda l=l: K.fused_attention_fwd_wide(xs[l], wws[l], H, pe, out=outs[l], ln=(gam, bet) + tuple(stats[l]),
+                                                        xn_out=xns[l])) for l in range(L)]
+        f_wp = [(lambda l=l: K.fused_attention_fwd_wide(xns[l], wws[l], H, pe, out=outs[l])) for l in range(L)]
         f_bw = [(lambda l=l: K.fused_attention_bwd(xns[l], ws[l], douts[l], H, pe, out=dqkvs[l], **grads)) for l in range(L)]
         t_ln, t_pl, t_bw = timed(f_ln), timed(f_pl), timed(f_bw)
+        t_wl, t_wp = timed(f_wl), timed(f_wp)
         print(f"B={B} {mode:11s} fwd+LN {t_ln:7.2f} us = {flop / t_ln / 1e6:6.0f} TF ({flop / t_ln / 1e6 / 25:4.1f} %)   "
-              f"fwd {t_pl:7.2f} us   bwd {t_bw:7.2f} us = {2 * flop / t_bw / 1e6:6.0f} TF", flush=True)
+              f"fwd {t_pl:7.2f} us   WIDE fwd+LN {t_wl:7.2f} us = {flop / t_wl / 1e6:6.0f} TF ({flop / t_wl / 1e6 / 25:4.1f} %)  fwd {t_wp:7.2f}   bwd {t_bw:7.2f} us = {2 * flop / t_bw / 1e6:6.0f} TF", flush=True)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,534 @@
+// Fused attention-with-positional-encoding forward on 32x32 matrix-core tiles ("wide" kernel, round 3): the
+// benchmark geometry N = 65 (64 patch tokens + class token), d = 192, 6 heads of 32, bf16.
+//
+// Replaces, per layer, reference models/vit.py:47-88 exactly as csrc/attn.hip does (qkv Linear without bias -> head
+// split -> RoPE rotate-half on the patch tokens, rope_utils.py:18-37 / vit.py:56-68 -> QK^T * hd^-0.5 -> + relative /
+// polynomial bias, positional_encoding.py:82-95 / 127-171 -> softmax -> @V -> merged heads), with the preceding
+// LayerNorm (vit.py:113,122) optionally applied while the tokens are staged.
+//
+// Why a second forward kernel.  The 16x16x32 kernel of attn.hip pads 65 tokens to 80 and spends 5.6 vector
+// instructions per MFMA; its counters say the vector issue port, not the matrix pipe, is what it runs out of (PMC,
+// 25 % of the wave-cycles issue, 47 % wait for an issue slot).  A 16x16x32 MFMA holds that port for 8
+// of its 16 cycles, a 32x32x16 MFMA for 8 of its 32 (MI355X_MICROARCH.md, issue-cost row) at twice the flop, and
+// 64 = 2 x 32: on 32-wide tiles the patch tokens need NO padding.  So:
+//   * tokens 0..63 (class token + 63 patches, natural order) are two 32-token tiles; token 64 is the "odd" token;
+//   * one wave per (image, head) as before, two images per workgroup, nothing of q/k/v in LDS;
+//   * V is projected un-swapped (A = x rows, B = Wv): the accumulators ARE the V^T operand of O^T = V^T P^T;
+//     K and Q swapped (A = W rows, B = x rows): the accumulators are the operands of S^T = K Q^T, RoPE in registers
+//     (the rotate-half partner f + 16 is register rho + 8 of the same lane);
+//   * weight fragments live in a 12-deep register ring: k-step s of the NEXT matrix is requested as soon as k-step s of
+//     the current one has been issued for both token tiles (a fragment is used twice, and requested a whole matrix
+//     ahead: ~12 k-steps of L2 latency cover);
+//   * the logits of a 32-query tile against all 64 keys are 2 x 16 registers per lane with the query on the lane:
+//     max and sum are in-lane plus one v_permlane32_swap; P is packed to bf16 in place and is the B operand of P.V;
+//   * the odd token: its q/k/v rows (2 images x 576 features) are projected ONCE per workgroup on 16x16x32 tiles
+//     (18 MFMAs per wave instead of a padded fifth tile = 36), exchanged through LDS behind one barrier; as a KEY it is
+//     one extra k-step whose A operand carries k_odd in every row; as a QUERY its 65 logits are produced with the keys
+//     on the lanes (A = q_odd in every row, B = K^T), so its softmax costs a 32-lane reduction instead of a whole tile.
+// Weights come from the "wide" pack (vitpe_pack_qkv_weights_wide): section 0 the 32x32x16 fragments, section 1 the
+// 16x16x32 fragments of the odd-token projection; the q rows are pre-multiplied by hd^-0.5 * log2(e) so that the
+// logits come out of the matrix core in the exp2 domain and no instruction scales q.
+#include "attn_common.h"
+#include <stdlib.h>
+
+namespace vitpe {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct W32 {
+  static constexpr int D = 192, HD = 32, H = 6, N = 65, P = 64, KS = 12, NTH = 768;
+  static constexpr int LDX = 200;    // token rows: 400 B = 25 16-B slots (odd): the 16 lanes a ds_read_b128 is served in hit 16 slots
+  static constexpr int CSLD = 20;    // cos / sin rows: 80 B = 5 slots (odd), same reason
+  static constexpr int XIMG = N * LDX;
+  static constexpr int WSCR = 256;   // bf16 elements of per-wave scratch: q_odd 0.., k_odd 32.., v_odd 64.., P row 128..
+};
+
+VITPE_DEV void mma32(const bf16x8& a, const bf16x8& b, f32x16& c) { c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+// registers 8s .. 8s+7 of a 32x32 accumulator tile as the operand fragment of k-step s of the next product
+// (cdna_hip_programming.md, "An accumulator tile as the next MFMA's operand"): position (lane half hh, element j) <->
+// accumulator row 16 s + 4 hh + (j & 3) + 8 (j >> 2) on BOTH operands of that product
+template <int S>
+VITPE_DEV bf16x8 pack8(const f32x16& a) {
+  bf16x8 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (bf16)a[8 * S + j];
+  return f;
+}
+
+VITPE_DEV bf16x8 ldsfrag(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+// max / sum over the 32 lanes of a half-wave (both halves hold the same data): xor 1, 2 by quad_perm, 4 and 8 by
+// row rotations of the 16-lane DPP rows, 16 by v_permlane16_swap
+#define VITPE_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
+VITPE_DEV float half_max(float v) {
+  v = fmaxf(v, VITPE_DPP(v, 0xB1));    // quad_perm [1,0,3,2]
+  v = fmaxf(v, VITPE_DPP(v, 0x4E));    // quad_perm [2,3,0,1]
+  v = fmaxf(v, VITPE_DPP(v, 0x124));   // row_ror:4
+  v = fmaxf(v, VITPE_DPP(v, 0x128));   // row_ror:8
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+VITPE_DEV float half_sum(float v) {
+  v += VITPE_DPP(v, 0xB1);
+  v += VITPE_DPP(v, 0x4E);
+  v += VITPE_DPP(v, 0x124);
+  v += VITPE_DPP(v, 0x128);
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+VITPE_DEV float swap32_max(float v) {
+  auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+VITPE_DEV float swap32_sum(float v) {
+  auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
+// KM: positional-encoding class (attn_common.h); LNF: LayerNorm fused into the staging; CENSUS: debug stamps
+template <int KM, bool LNF, bool CENSUS = false>
+__global__ __launch_bounds__(768, 3) void attn32_fwd_kernel(AttnArgs a) {
+  using C = AttnCfg<bf16, 32, 192, 5, 1, 65>;   // (bias-table helpers of attn_common.h: TABLD = 160, PBLD = 32)
+  constexpr int D = W32::D, N = W32::N, LDX = W32::LDX, CSLD = W32::CSLD, H = W32::H;
+  __shared__ __attribute__((aligned(16))) bf16 xs_all[2 * W32::XIMG];
+  __shared__ __attribute__((aligned(16))) float s_cos[KM == KM_ROPE ? H * N * CSLD : 4];   // [table][token][CSLD]; token 0 = identity
+  __shared__ __attribute__((aligned(16))) float s_sin[KM == KM_ROPE ? H * N * CSLD : 4];
+  __shared__ __attribute__((aligned(16))) float odd_raw[2 * 3 * D];                          // [image][head][q|k|v][32] of token 64
+  __shared__ __attribute__((aligned(16))) bf16 wscr[12 * W32::WSCR];
+  __shared__ __attribute__((aligned(16))) float s_tab[KM == KM_RELATIVE ? C::H * C::TABLD : 4];
+  __shared__ __attribute__((aligned(16))) float s_coef[KM == KM_POLY ? C::PESZ : 4];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int img = wave & 1, h = wave >> 1;       // partner waves (same head, the two images) are neighbours: they stream
+  const int b_raw = blockIdx.x * 2 + img;        // the same weight fragments at the same time
+  const bool live = b_raw < a.B;                 // odd batch: the last workgroup's second image is a copy that stores nothing
+  const int b = live ? b_raw : a.B - 1;
+  const int r = lane & 31, hh = lane >> 5;
+  auto stamp = [&](int slot) {
+    if (CENSUS) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (lane == 0) a.census[((size_t)blockIdx.x * 16 + wave) * 8 + slot] = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  stamp(0);
+  const bf16* const Wbase = reinterpret_cast<const bf16*>(a.wqkv);
+  const bf16* const Wh = Wbase + ((size_t)h * 3 * W32::KS * 64 + lane) * 8;              // + (mat * 12 + s) * 512
+  const bf16* const Wodd = Wbase + (size_t)3 * D * D + ((size_t)wave * 18 * 64 + lane) * 8;   // + i * 512, i < 18
+
+  // ---- the odd-token projection's 18 weight fragments (16x16x32 shape) fly under the token staging
+  bf16x8 wo[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) wo[i] = *reinterpret_cast<const bf16x8*>(Wodd + (size_t)i * 512);
+
+  // ---- stage both images' tokens (LayerNorm on the way in), the PE tables
+  {
+    const int simg = tid / 384, st = tid % 384, cc = st % 24, r0 = st / 24;
+    const int sb_raw = blockIdx.x * 2 + simg;
+    const bool slive = sb_raw < a.B;
+    const int sb = slive ? sb_raw : a.B - 1;
+    const bf16* xg = reinterpret_cast<const bf16*>(a.xn) + (size_t)sb * N * D + cc * 8;
+    Chunk16 v[5];
+    float mu[5], rs[5];
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+      const int rowc = min(r0 + 16 * it, N - 1);
+      v[it] = *reinterpret_cast<const Chunk16*>(xg + (size_t)rowc * D);
+      mu[it] = LNF ? a.ln_mean[(size_t)sb * N + rowc] : 0.f;
+      rs[it] = LNF ? a.ln_rstd[(size_t)sb * N + rowc] : 0.f;
+    }
+    if (LNF) {
+      float gq[8], bq[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { gq[t] = a.ln_gamma[cc * 8 + t]; bq[t] = a.ln_beta[cc * 8 + t]; }
+      bf16* xo = (a.xn_out != nullptr && slive) ? reinterpret_cast<bf16*>(a.xn_out) + (size_t)sb * N * D + cc * 8 : nullptr;
+#pragma unroll
+      for (int it = 0; it < 5; ++it) {
+        const int row = r0 + 16 * it;
+        if (row < N) {
+          float f[8];
+          chunk_to_f32<bf16>(v[it], f);
+          const float sc = rs[it], sh = -mu[it] * rs[it];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) f[t] = fmaf(fmaf(f[t], sc, sh), gq[t], bq[t]);
+          v[it] = f32_to_chunk<bf16>(f);
+          if (xo != nullptr) __builtin_nontemporal_store(v[it], reinterpret_cast<Chunk16*>(xo + (size_t)row * D));   // read again only in backward
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+      const int row = r0 + 16 * it;
+      if (row < N) *reinterpret_cast<Chunk16*>(xs_all + simg * W32::XIMG + row * LDX + cc * 8) = v[it];
+    }
+    if (KM == KM_ROPE) {   // cos / sin -> LDS indexed by TOKEN; the class token's row is the identity rotation (vit.py:56-68)
+      const int ntab = (a.mode == PE_ROPE_MIXED) ? H : 1;
+      for (int q = tid; q < ntab * N * 4; q += W32::NTH) {
+        const int f4 = q & 3, row = (q >> 2) % N, t = (q >> 2) / N;
+        f32x4 cv = {1.f, 1.f, 1.f, 1.f}, sv = {0.f, 0.f, 0.f, 0.f};
+        if (row >= 1) {
+          const size_t src = ((size_t)t * (N - 1) + row - 1) * 16 + 4 * f4;
+          cv = *reinterpret_cast<const f32x4*>(a.cos + src);
+          sv = *reinterpret_cast<const f32x4*>(a.sin + src);
+        }
+        *reinterpret_cast<f32x4*>(&s_cos[(t * N + row) * CSLD + 4 * f4]) = cv;
+        *reinterpret_cast<f32x4*>(&s_sin[(t * N + row) * CSLD + 4 * f4]) = sv;
+      }
+    }
+    if (KM == KM_RELATIVE) {
+      for (int q = tid; q < C::H * C::TABLD; q += W32::NTH) {
+        const int hq = q / C::TABLD, i = q % C::TABLD;
+        s_tab[q] = (i < 2 * N - 1) ? a.table[hq * (2 * N - 1) + i] * LOG2E : 0.f;
+      }
+    }
+    if (KM == KM_POLY) stage_poly<C>(a, 0, s_coef, N, tid, W32::NTH);
+  }
+  stamp(1);
+  __syncthreads();
+  stamp(2);
+
+  // ---- weight ring: Wv first (its latency runs under the odd-token projection)
+  bf16x8 w[12];
+#pragma unroll
+  for (int s = 0; s < 12; ++s) w[s] = *reinterpret_cast<const bf16x8*>(Wh + (size_t)(2 * 12 + s) * 512);
+
+  // ---- odd token (row 64 of both images): wave takes feature tiles 3 wave .. 3 wave + 2 of the 36 (flat feature
+  //      index 16 ft + ... = head * 96 + {q,k,v} * 32 + f); B operand = the two rows, image = column & 1
+  {
+    const int c = lane & 15, g = lane >> 4;
+    const bf16* xo = xs_all + (c & 1) * W32::XIMG + 64 * LDX + 8 * g;
+    Frag<bf16> xf[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) xf[ks].v = ldsfrag(xo + 32 * ks);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo[t * 6 + ks], xf[ks].v, acc, 0, 0, 0);
+      if (c < 2) *reinterpret_cast<f32x4*>(&odd_raw[c * 3 * D + 16 * (3 * wave + t) + 4 * g]) = acc;
+    }
+  }
+  __syncthreads();
+  const int cs_tab = (KM == KM_ROPE && a.mode == PE_ROPE_MIXED) ? h * N * CSLD : 0;
+  bf16* const ws = wscr + wave * W32::WSCR;
+  {  // rotate the odd token's q and k (token 64 = grid position 63), park q | k | v as bf16 in this wave's scratch
+    const float* raw = odd_raw + img * 3 * D + h * 96;
+    const int m = lane >> 5, f = lane & 31, fl = f & 15;        // lanes 0-31: q, 32-63: k
+    float val;
+    if (KM == KM_ROPE) {
+      const float x1 = raw[m * 32 + fl], x2 = raw[m * 32 + fl + 16];
+      const float cv = s_cos[cs_tab + 64 * CSLD + fl], sv = s_sin[cs_tab + 64 * CSLD + fl];
+      val = (f < 16) ? x1 * cv - x2 * sv : x1 * sv + x2 * cv;
+    } else {
+      val = raw[m * 32 + f];
+    }
+    ws[m * 32 + f] = (bf16)val;
+    if (lane < 32) ws[64 + lane] = (bf16)raw[64 + lane];
+  }
+  stamp(3);
+
+  const bf16* const xr0 = xs_all + img * W32::XIMG + r * LDX + 8 * hh;   // token tile 0, k-step s: + 16 s
+  const bf16* const xr1 = xr0 + 32 * LDX;
+  const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // ---- v, un-swapped: acc[rho] = v[token 32 t + perm(rho, hh)][feature r] -> V^T operand fragments
+  bf16x8 vf[4];
+  {
+    f32x16 a0 = z16, a1 = z16;
+#pragma unroll
+    for (int s = 0; s < 12; ++s) {
+      const bf16x8 xa = ldsfrag(xr0 + 16 * s), xb = ldsfrag(xr1 + 16 * s);
+      mma32(xa, w[s], a0);
+      mma32(xb, w[s], a1);
+      w[s] = *reinterpret_cast<const bf16x8*>(Wh + (size_t)(1 * 12 + s) * 512);   // Wk's k-step s takes the ring slot
+    }
+    vf[0] = pack8<0>(a0); vf[1] = pack8<1>(a0); vf[2] = pack8<0>(a1); vf[3] = pack8<1>(a1);
+  }
+  stamp(4);
+
+  // ---- k and q, swapped: acc[rho] = k[token 32 t + r][feature perm(rho, hh)]; rotate; -> fragments
+  auto rope = [&](f32x16& acc, int tile) {
+    if (KM == KM_ROPE) {
+      const int tok = 32 * tile + r;
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(&s_cos[cs_tab + tok * CSLD + 4 * hh]);
+      const f32x4 c1 = *reinterpret_cast<const f32x4*>(&s_cos[cs_tab + tok * CSLD + 8 + 4 * hh]);
+      const f32x4 n0 = *reinterpret_cast<const f32x4*>(&s_sin[cs_tab + tok * CSLD + 4 * hh]);
+      const f32x4 n1 = *reinterpret_cast<const f32x4*>(&s_sin[cs_tab + tok * CSLD + 8 + 4 * hh]);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {   // feature f = (q & 3) + 8 (q >> 2) + 4 hh < 16 pairs with f + 16 = register q + 8
+        const float cv = (q < 4) ? c0[q & 3] : c1[q & 3], sv = (q < 4) ? n0[q & 3] : n1[q & 3];
+        const float x1 = acc[q], x2 = acc[q + 8];
+        acc[q] = x1 * cv - x2 * sv;
+        acc[q + 8] = x1 * sv + x2 * cv;
+      }
+    }
+  };
+  bf16x8 kf[2][2], qf[2][2];
+  {
+    f32x16 a0 = z16, a1 = z16;
+#pragma unroll
+    for (int s = 0; s < 12; ++s) {
+      const bf16x8 xa = ldsfrag(xr0 + 16 * s), xb = ldsfrag(xr1 + 16 * s);
+      mma32(w[s], xa, a0);
+      mma32(w[s], xb, a1);
+      w[s] = *reinterpret_cast<const bf16x8*>(Wh + (size_t)(0 * 12 + s) * 512);   // Wq
+    }
+    rope(a0, 0);
+    rope(a1, 1);
+    kf[0][0] = pack8<0>(a0); kf[0][1] = pack8<1>(a0); kf[1][0] = pack8<0>(a1); kf[1][1] = pack8<1>(a1);
+  }
+  stamp(5);
+  {
+    f32x16 a0 = z16, a1 = z16;
+#pragma unroll
+    for (int s = 0; s < 12; ++s) {
+      const bf16x8 xa = ldsfrag(xr0 + 16 * s), xb = ldsfrag(xr1 + 16 * s);
+      mma32(w[s], xa, a0);
+      mma32(w[s], xb, a1);
+    }
+    rope(a0, 0);
+    rope(a1, 1);
+    qf[0][0] = pack8<0>(a0); qf[0][1] = pack8<1>(a0); qf[1][0] = pack8<0>(a1); qf[1][1] = pack8<1>(a1);
+  }
+  stamp(6);
+
+  // ---- the odd token's operand fragments from the wave scratch: position (hh, j) <-> feature 16 s + 4 hh + (j & 3) + 8 (j >> 2)
+  auto odd_rows = [&](int base, bf16x8 (&f)[2]) {   // every row (A operand) / column (B operand) = the odd token's vector
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x4 lo = *reinterpret_cast<const bf16x4*>(ws + base + 16 * s + 4 * hh);
+      const bf16x4 hi = *reinterpret_cast<const bf16x4*>(ws + base + 16 * s + 8 + 4 * hh);
+      f[s] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+  bf16x8 kfo[2];
+  odd_rows(32, kfo);
+  bf16x8 vfo;   // A operand [feature r][k position]: v_odd at position (hh 0, j 0), zero elsewhere
+  {
+    const bf16 vv = ws[64 + r];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vfo[j] = (bf16)0.f;
+    vfo[0] = (hh == 0) ? vv : (bf16)0.f;
+  }
+
+  bf16* const outp = reinterpret_cast<bf16*>(a.out) + (size_t)b * N * D + h * 32;
+  // O^T accumulators -> scaled bf16 rows: lane (query r, hh) holds features 8 m + 4 hh .. + 3 in registers 4 m .. 4 m + 3;
+  // one v_permlane32_swap per dword pairs the halves' 8-B pieces into 16 contiguous bytes (features 16 mp + 8 hh .. + 7)
+  auto store_rows = [&](const f32x16& o, float inv, int token, bool pred) {
+#pragma unroll
+    for (int mp = 0; mp < 2; ++mp) {
+      uint32_t d0[2], d1[2];
+#pragma unroll
+      for (int w2 = 0; w2 < 2; ++w2) {
+        bf16x2 pa, pb;
+        pa[0] = (bf16)(o[8 * mp + 2 * w2] * inv); pa[1] = (bf16)(o[8 * mp + 2 * w2 + 1] * inv);           // piece m = 2 mp
+        pb[0] = (bf16)(o[8 * mp + 4 + 2 * w2] * inv); pb[1] = (bf16)(o[8 * mp + 4 + 2 * w2 + 1] * inv);   // piece m = 2 mp + 1
+        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, pa), __builtin_bit_cast(uint32_t, pb), false, false);
+        d0[w2] = sw[0]; d1[w2] = sw[1];
+      }
+      if (pred) *reinterpret_cast<Chunk16*>(outp + (size_t)token * D + 16 * mp + 8 * hh) = (Chunk16){d0[0], d0[1], d1[0], d1[1]};
+    }
+  };
+
+  // ---- per 32-query tile: S^T = K Q^T (+ bias), softmax in the exp2 domain, O^T = V^T P^T, store
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    __builtin_amdgcn_sched_barrier(0);
+    const int i = 32 * qt + r;
+    f32x16 so = z16, s0 = z16, s1 = z16;
+    mma32(kfo[0], qf[qt][0], so);
+    mma32(kf[0][0], qf[qt][0], s0);
+    mma32(kf[1][0], qf[qt][0], s1);
+    mma32(kfo[1], qf[qt][1], so);
+    mma32(kf[0][1], qf[qt][1], s0);
+    mma32(kf[1][1], qf[qt][1], s1);
+    float sodd = so[0];                              // every row of that tile is the odd key
+    if (KM == KM_RELATIVE || KM == KM_POLY) {
+      sodd += pe_bias2<C, KM>(a, s_tab, s_coef, h, i, 64, N);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int j = (q & 3) + 8 * (q >> 2) + 4 * hh;
+        s0[q] += pe_bias2<C, KM>(a, s_tab, s_coef, h, i, j, N);
+        s1[q] += pe_bias2<C, KM>(a, s_tab, s_coef, h, i, 32 + j, N);
+      }
+    }
+    float m = sodd;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) m = fmaxf(m, fmaxf(s0[q], s1[q]));
+    m = swap32_max(m);
+    float l = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      s0[q] = __builtin_amdgcn_exp2f(s0[q] - m);
+      s1[q] = __builtin_amdgcn_exp2f(s1[q] - m);
+      l += s0[q] + s1[q];
+    }
+    const float podd = __builtin_amdgcn_exp2f(sodd - m);
+    l = swap32_sum(l) + podd;
+    bf16x8 pfo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pfo[j] = (bf16)0.f;
+    pfo[0] = (bf16)podd;                             // (meets zeros of vfo everywhere but at position (0, 0))
+    f32x16 o = z16;
+    mma32(vf[0], pack8<0>(s0), o);
+    mma32(vf[1], pack8<1>(s0), o);
+    mma32(vf[2], pack8<0>(s1), o);
+    mma32(vf[3], pack8<1>(s1), o);
+    mma32(vfo, pfo, o);
+    store_rows(o, __builtin_amdgcn_rcpf(l), i, live);
+  }
+
+  // ---- the odd token as a query: logits with the KEY on the lane (A = q_odd in every row, B = K^T), softmax by a
+  //      32-lane reduction, P through the wave scratch into the B-operand order, O^T row stored from lanes 0 and 32
+  {
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 qfo[2];
+    odd_rows(0, qfo);
+    f32x16 t0 = z16, t1 = z16, t2 = z16;
+    mma32(qfo[0], kf[0][0], t0);
+    mma32(qfo[0], kf[1][0], t1);
+    mma32(qfo[0], kfo[0], t2);
+    mma32(qfo[1], kf[0][1], t0);
+    mma32(qfo[1], kf[1][1], t1);
+    mma32(qfo[1], kfo[1], t2);
+    float a0 = t0[0], a1 = t1[0], a2 = t2[0];        // keys r, 32 + r, 64 (all rows equal)
+    if (KM == KM_RELATIVE || KM == KM_POLY) {
+      a0 += pe_bias2<C, KM>(a, s_tab, s_coef, h, 64, r, N);
+      a1 += pe_bias2<C, KM>(a, s_tab, s_coef, h, 64, 32 + r, N);
+      a2 += pe_bias2<C, KM>(a, s_tab, s_coef, h, 64, 64, N);
+    }
+    const float m = half_max(fmaxf(fmaxf(a0, a1), a2));
+    const float p0 = __builtin_amdgcn_exp2f(a0 - m), p1 = __builtin_amdgcn_exp2f(a1 - m), p2 = __builtin_amdgcn_exp2f(a2 - m);
+    const float l = half_sum(p0 + p1) + p2;
+    bf16* const pr = ws + 128;
+    if (hh == 0) { pr[r] = (bf16)p0; pr[32 + r] = (bf16)p1; }
+    __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): this wave's own LDS writes have landed
+    bf16x8 pq[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x4 lo = *reinterpret_cast<const bf16x4*>(pr + 16 * ks + 4 * hh);
+      const bf16x4 hi = *reinterpret_cast<const bf16x4*>(pr + 16 * ks + 8 + 4 * hh);
+      pq[ks] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    bf16x8 pfo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pfo[j] = (bf16)0.f;
+    pfo[0] = (bf16)p2;
+    f32x16 o = z16;
+    mma32(vf[0], pq[0], o);
+    mma32(vf[1], pq[1], o);
+    mma32(vf[2], pq[2], o);
+    mma32(vf[3], pq[3], o);
+    mma32(vfo, pfo, o);
+    store_rows(o, __builtin_amdgcn_rcpf(l), 64, live && r == 0);
+  }
+  stamp(7);
+}
+
+// ---- the wide pack ------------------------------------------------------------------------------------------------
+// section 0 [3 D D elements]: block ((h * 3 + mat) * 12 + s) = 64 lanes x 8: lane (r = l & 31, hh = l >> 5), element j =
+//   W[mat D + 32 h + r][16 s + 8 hh + j]                       (32x32x16 operand fragments)
+// section 1 [3 D D elements]: block ((h * 3 + mat) * 2 + nt) * 6 + ks: lane (c = l & 15, g = l >> 4), element e =
+//   W[mat D + 32 h + 16 nt + c][32 ks + 8 g + e]               (16x16x32 fragments of the odd-token projection)
+// both with the q rows (mat 0) multiplied by qscale = hd^-0.5 * log2(e)
+VITPE_DEV void wide_src(long long idx, int D, int& row, int& col, int& mat) {
+  const long long sec = idx / ((long long)3 * D * D);
+  long long t = idx % ((long long)3 * D * D);
+  const int e = (int)(t & 7), l = (int)((t >> 3) & 63);
+  long long blk = t >> 9;
+  if (sec == 0) {
+    const int S = D / 16;
+    const int s = (int)(blk % S); blk /= S;
+    mat = (int)(blk % 3);
+    const int h = (int)(blk / 3);
+    row = mat * D + 32 * h + (l & 31);
+    col = 16 * s + 8 * (l >> 5) + e;
+  } else {
+    const int KS = D / 32;
+    const int ks = (int)(blk % KS); blk /= KS;
+    const int nt = (int)(blk % 2); blk /= 2;
+    mat = (int)(blk % 3);
+    const int h = (int)(blk / 3);
+    row = mat * D + 32 * h + 16 * nt + (l & 15);
+    col = 32 * ks + 8 * (l >> 4) + e;
+  }
+}
+__global__ void pack_qkv_wide_kernel(const float* __restrict__ w, bf16* __restrict__ dst, int D, float qscale) {
+  const long long total = (long long)6 * D * D;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    int row, col, mat;
+    wide_src(idx, D, row, col, mat);
+    dst[idx] = (bf16)(w[(size_t)row * D + col] * (mat == 0 ? qscale : 1.0f));
+  }
+}
+
+}  // namespace vitpe
+
+using namespace vitpe;
+
+extern "C" int vitpe_fused_attention_wide_supported(int dtype, int N, int D, int HD) {
+  return dtype == 1 && N == 65 && D == 192 && HD == 32;
+}
+
+extern "C" int vitpe_qkv_wide_pack_elems(int D) { return 6 * D * D; }
+
+extern "C" int vitpe_pack_qkv_weights_wide(int dtype, const float* wqkv, void* packed, int D, int HD, hipStream_t stream) {
+  VITPE_REQUIRE(wqkv && packed && dtype == 1 && HD == 32 && D > 0 && D % 32 == 0);
+  const long long total = (long long)6 * D * D;
+  const unsigned blocks = (unsigned)min((total + 255) / 256, (long long)2048);
+  hipLaunchKernelGGL(pack_qkv_wide_kernel, dim3(blocks), dim3(256), 0, stream, wqkv, (bf16*)packed, D,
+                     LOG2E / sqrtf((float)HD));
+  VITPE_CHECK_LAUNCH();
+}
+
+template <int KM>
+static int launch_wide(const AttnArgs& a, hipStream_t s) {
+  const dim3 grid((a.B + 1) / 2), block(768);
+  if (a.ln_gamma != nullptr) hipLaunchKernelGGL((attn32_fwd_kernel<KM, true>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((attn32_fwd_kernel<KM, false>), grid, block, 0, s, a);
+  VITPE_CHECK_LAUNCH();
+}
+
+// vitpe_fused_attention_fwd(_ln) on the wide kernel: wqkv_wide = vitpe_pack_qkv_weights_wide; gamma == NULL: x is already
+// layer-normed (mean / rstd / xn_out ignored)
+extern "C" int vitpe_fused_attention_fwd_wide(int dtype, const void* x, const float* gamma, const float* beta,
+                                              const float* mean, const float* rstd, void* xn_out,
+                                              const void* wqkv_wide, void* out, int B, int N, int D, int HD, int mode,
+                                              const float* cos, const float* sin, const float* table,
+                                              const float* coeff, int grid, int degree, int coeff_per_head,
+                                              hipStream_t stream) {
+  VITPE_REQUIRE(x && wqkv_wide && out && B >= 0);
+  if (!vitpe_fused_attention_wide_supported(dtype, N, D, HD)) return (int)hipErrorNotSupported;
+  if (gamma != nullptr) VITPE_REQUIRE(beta && mean && rstd);
+  if (mode == PE_ROPE_AXIAL || mode == PE_ROPE_MIXED) VITPE_REQUIRE(cos && sin && grid * grid == N - 1);
+  if (mode == PE_RELATIVE) VITPE_REQUIRE(table != nullptr);
+  if (mode == PE_POLY) VITPE_REQUIRE(coeff && degree >= 0 && degree <= 7 && grid * grid == N - 1);
+  VITPE_REQUIRE(mode >= PE_NONE && mode <= PE_ROPE_MIXED);
+  if (B == 0) return 0;
+  AttnArgs a{};
+  a.xn = x; a.wqkv = wqkv_wide; a.out = out; a.cos = cos; a.sin = sin; a.table = table; a.coeff = coeff;
+  a.ln_gamma = gamma; a.ln_beta = beta; a.ln_mean = mean; a.ln_rstd = rstd; a.xn_out = gamma ? xn_out : nullptr;
+  a.B = B; a.N = N; a.mode = mode; a.grid = grid; a.degree = degree; a.coeff_per_head = coeff_per_head;
+  a.scale = 1.0f / sqrtf((float)HD);
+  switch (mode) {
+    case PE_RELATIVE: return launch_wide<KM_RELATIVE>(a, stream);
+    case PE_POLY: return launch_wide<KM_POLY>(a, stream);
+    case PE_ROPE_AXIAL:
+    case PE_ROPE_MIXED: return launch_wide<KM_ROPE>(a, stream);
+    default: return launch_wide<KM_PLAIN>(a, stream);
+  }
+}
+
+// debug: phase census of the wide forward (rope-axial, no LayerNorm): census[(workgroup * 16 + wave) * 8 + slot] =
+// s_memtime at 0 start, 1 staged, 2 barrier passed, 3 odd token projected + exchanged, 4 v, 5 k, 6 q, 7 end
+extern "C" int vitpe_debug_attn32_census(const void* xn, const void* wqkv_wide, void* out, const float* cos,
+                                         const float* sin, int B, unsigned long long* census, hipStream_t stream) {
+  VITPE_REQUIRE(xn && wqkv_wide && out && cos && sin && census && B > 0);
+  AttnArgs a{};
+  a.xn = xn; a.wqkv = wqkv_wide; a.out = out; a.cos = cos; a.sin = sin; a.B = B; a.N = 65; a.mode = PE_ROPE_AXIAL; a.grid = 8;
+  a.scale = 0.17677669f; a.census = census;
+  hipLaunchKernelGGL((attn32_fwd_kernel<KM_ROPE, false, true>), dim3((B + 1) / 2), dim3(768), 0, stream, a);
+  VITPE_CHECK_LAUNCH();
+}

@@ -435,6 +435,41 @@ def fused_attention_fwd(xn, wqkv, num_heads, pe: PETables, out=None, ln=None, xn
     return o
 
 
+def fused_attention_wide_supported(dtype, N, D, HD) -> bool:
+    return bool(lib().vitpe_fused_attention_wide_supported(dtype_code(dtype), N, D, HD))
+
+
+def pack_qkv_weights_wide(wqkv_f32, dtype, num_heads, out=None):
+    """fp32 master [3D,D] -> the wide pack of the 32x32-tile forward kernel (include/vitpe.h: 6 D D elements, q rows
+    pre-multiplied by hd^-0.5 log2 e)."""
+    require_device(wqkv_f32, out)
+    _f32(wqkv_f32, "wqkv")
+    D = wqkv_f32.shape[1]
+    n = lib().vitpe_qkv_wide_pack_elems(D)
+    o = out if out is not None else torch.empty(n, dtype=dtype, device=wqkv_f32.device)
+    assert o.numel() == n and o.dtype == dtype
+    check(lib().vitpe_pack_qkv_weights_wide(dtype_code(dtype), ptr(wqkv_f32), ptr(o), D, D // num_heads, stream_ptr()),
+          "vitpe_pack_qkv_weights_wide")
+    return o
+
+
+def fused_attention_fwd_wide(xn, wqkv_wide, num_heads, pe: PETables, out=None, ln=None, xn_out=None):
+    """fused_attention_fwd on the 32x32-tile kernel (bf16, N = 65, D = 192, hd = 32); wqkv_wide = pack_qkv_weights_wide."""
+    require_device(xn, wqkv_wide, pe.cos, pe.sin, pe.table, pe.coeff, out, xn_out)
+    B, N, D = xn.shape
+    HD = D // num_heads
+    assert wqkv_wide.numel() == 6 * D * D and wqkv_wide.dtype == xn.dtype
+    o = out if out is not None else torch.empty_like(xn)
+    g = ln if ln is not None else (None, None, None, None)
+    if ln is not None:
+        require_device(*ln)
+    check(lib().vitpe_fused_attention_fwd_wide(dtype_code(xn.dtype), ptr(xn), ptr(g[0]), ptr(g[1]), ptr(g[2]), ptr(g[3]),
+                                               ptr(xn_out), ptr(wqkv_wide), ptr(o), B, N, D, HD, pe.code, ptr(pe.cos),
+                                               ptr(pe.sin), ptr(pe.table), ptr(pe.coeff), pe.grid, pe.degree,
+                                               int(pe.coeff_per_head), stream_ptr()), "vitpe_fused_attention_fwd_wide")
+    return o
+
+
 def fused_attention_bwd(xn, wqkv, dout, num_heads, pe: PETables, dtable=None, dcoeff=None, dfreqs=None, out=None, ln=None):
     """-> dqkv [B,N,3D]; PE-parameter gradients accumulated into dtable/dcoeff/dfreqs.  ln=(gamma, beta, mean, rstd):
     `xn` holds the RAW tokens and the LayerNorm is recomputed while staging them (nothing normalised was stored)."""
