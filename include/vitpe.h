@@ -77,9 +77,9 @@ int vitpe_fused_attention_fwd_ln(int dtype, const void* x, const float* gamma, c
                                  int degree, int coeff_per_head, vitpe_stream_t stream);
 /* ---- the "wide" forward: 32x32x16 matrix-core tiles for the benchmark geometry (bf16, N = 65, D = 192, HD = 32) ------
  * Same operation as vitpe_fused_attention_fwd(_ln) (reference models/vit.py:47-88, LayerNorm vit.py:113,122 optional),
- * on weights packed by vitpe_pack_qkv_weights_wide: vitpe_qkv_wide_pack_elems(D) = 6 D D elements of T --
- * section 0 the 32x32x16 operand fragments (block (head, {q,k,v}, 16-deep k step) x 64 lanes x 8), section 1 the
- * 16x16x32 fragments of the 65th token's projection; the q rows are pre-multiplied by HD^-0.5 * log2(e).
+ * on weights packed by vitpe_pack_qkv_weights_wide: vitpe_qkv_wide_pack_elems(D) = 3 D D elements of T, the
+ * 32x32x16 operand fragments (block (head, {q,k,v}, 16-deep k step) x 64 lanes x 8 = 1 KB, what one LDS-DMA
+ * instruction moves); the q rows are pre-multiplied by HD^-0.5 * log2(e).
  * gamma == NULL: x is already layer-normed (beta / mean / rstd / xn_out ignored).  Other shapes: hipErrorNotSupported. */
 int vitpe_fused_attention_wide_supported(int dtype, int N, int D, int HD);
 int vitpe_qkv_wide_pack_elems(int D);

@@ -23,8 +23,9 @@ int vitpe_debug_wgrad_census(int dtype, const vitpe_wgrad_problem* problems, int
  * 4 k projected, 5 q projected, 6 end                                                                              */
 int vitpe_debug_attn_census(const void* xn, const void* wqkv, void* out, const float* cos, const float* sin,
                             int B, unsigned long long* census, vitpe_stream_t stream);
-/* the same for the wide forward (csrc/attn32.hip; wqkv_wide = vitpe_pack_qkv_weights_wide): slots 0 start, 1 staged,
- * 2 barrier passed, 3 65th token projected + exchanged, 4 v, 5 k, 6 q, 7 end                                       */
+/* the same for the wide forward (csrc/attn32.hip; wqkv_wide = vitpe_pack_qkv_weights_wide): 16 slots per wave: 0 start,
+ * 1 staged, 2 barrier passed, 3 projection k-loop done, 4 operand fragments built, 5 patch queries done, 6 end, 8 cycles in
+ * the k-loop's barriers, 9 / 10 s_memrealtime (100 MHz) at start / end                                       */
 int vitpe_debug_attn32_census(const void* xn, const void* wqkv_wide, void* out, const float* cos, const float* sin,
                               int B, unsigned long long* census, vitpe_stream_t stream);
 /* phase census of the second-generation block tail (training instantiation with stamps; bf16, D = 192):

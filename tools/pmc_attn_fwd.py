@@ -9,7 +9,10 @@ T, dev = torch.bfloat16, "cuda"
 mode = os.environ.get("KB_MODE", "rope-axial")
 r = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(T)  # noqa: E731
 xs, outs, xns = ([r(B, N, D) for _ in range(L)] for _ in range(3))
-ws = [K.pack_qkv_weights(torch.randn(3 * D, D, device=dev) * 0.1, T, H) for _ in range(L)]
+wide = os.environ.get('KB_WIDE', '1') == '1'
+Ws = [torch.randn(3 * D, D, device=dev) * 0.1 for _ in range(L)]
+ws = [(K.pack_qkv_weights_wide if wide else K.pack_qkv_weights)(w_, T, H) for w_ in Ws]
+fwd = K.fused_attention_fwd_wide if wide else K.fused_attention_fwd
 gam, bet = torch.ones(D, device=dev), torch.zeros(D, device=dev)
 stats = [K.layernorm_fwd(x, gam, bet, stats_only=True)[1:] for x in xs]
 pe = K.PETables(mode, 8)
@@ -24,5 +27,5 @@ elif mode == "polynomial":
     pe.coeff, pe.degree = torch.randn(4, device=dev) * 0.02, 3
 for _ in range(4):
     for l in range(L):
-        K.fused_attention_fwd(xs[l], ws[l], H, pe, out=outs[l], ln=(gam, bet) + tuple(stats[l]), xn_out=xns[l])
+        fwd(xs[l], ws[l], H, pe, out=outs[l], ln=(gam, bet) + tuple(stats[l]), xn_out=xns[l])
 torch.cuda.synchronize()

@@ -57,6 +57,15 @@ VITPE_DEV bf16x8 pack8(const f32x16& a) {
 }
 
 VITPE_DEV bf16x8 ldsfrag(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+// (fmaxf on matrix-core outputs costs a canonicalising v_max per operand; the logits are finite by construction)
+VITPE_DEV float max3(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// the same LDS address read again in a later phase must be a NEW read: left alone, the compiler keeps all 24 token
+// fragments of the first projection alive for the other two (96 registers) and spills
+VITPE_DEV const bf16* fresh(const bf16* p) { asm volatile("" : "+v"(p)); return p; }
 
 // max / sum over the 32 lanes of a half-wave (both halves hold the same data): xor 1, 2 by quad_perm, 4 and 8 by
 // row rotations of the 16-lane DPP rows, 16 by v_permlane16_swap
@@ -86,42 +95,67 @@ VITPE_DEV float swap32_sum(float v) {
   return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
-// KM: positional-encoding class (attn_common.h); LNF: LayerNorm fused into the staging; CENSUS: debug stamps
-template <int KM, bool LNF, bool CENSUS = false>
+// KM: positional-encoding class (attn_common.h); LNF: LayerNorm fused into the staging; MIXED: per-head cos / sin
+// tables (rope-mixed); CENSUS: debug stamps
+//
+// Projection = one workgroup-synchronous k-loop over six 32-deep chunks.  Chunk c of EVERY head's Wq / Wk / Wv (36 1-KB
+// fragments) is brought into LDS once per workgroup by LDS-DMA (three pieces per wave, a chunk ahead, two buffers);
+// a wave reads, per 16-deep k-step, two token fragments and its head's three weight fragments and issues six MFMAs into
+// SIX live accumulators (v, k, q of both token tiles: 96 registers): every operand byte is read from LDS exactly once
+// and every weight byte leaves L2 once per workgroup (the register-ring version fetched 648 KB per CU from L2 -- each
+// wave its own copy -- and its projection phases ran at the L2 -> CU rate, census in DESIGN.md).  The odd token's
+// 16x16x32 operands are gathered from the same LDS image (a 16x16x32 fragment is a different lane -> address map of two
+// consecutive 32x32x16 fragments), three feature tiles per wave and chunk.
+template <int KM, bool LNF, bool MIXED, bool CENSUS = false>
 __global__ __launch_bounds__(768, 3) void attn32_fwd_kernel(AttnArgs a) {
   using C = AttnCfg<bf16, 32, 192, 5, 1, 65>;   // (bias-table helpers of attn_common.h: TABLD = 160, PBLD = 32)
-  constexpr int D = W32::D, N = W32::N, LDX = W32::LDX, CSLD = W32::CSLD, H = W32::H;
+  constexpr int D = W32::D, N = W32::N, LDX = W32::LDX, H = W32::H;
+  constexpr int CSLD = MIXED ? 16 : W32::CSLD;   // (mixed: unpadded rows, or the six tables would not fit the token region)
+  constexpr int NPIECE = 36, WBUF = NPIECE * 512;   // one chunk: (head, matrix, k-step in chunk) x 1 KB
+  // rope-mixed: the per-head tables (62 KB) do not fit beside the weight ring; they are staged into the token region
+  // once the projections are done with it
+  constexpr int CSTAB = (KM != KM_ROPE) ? 4 : (MIXED ? 4 : N * CSLD);
+  static_assert(!MIXED || H * N * CSLD * 4 * 2 <= 2 * W32::XIMG * 2, "mixed tables must fit the token region");
   __shared__ __attribute__((aligned(16))) bf16 xs_all[2 * W32::XIMG];
-  __shared__ __attribute__((aligned(16))) float s_cos[KM == KM_ROPE ? H * N * CSLD : 4];   // [table][token][CSLD]; token 0 = identity
-  __shared__ __attribute__((aligned(16))) float s_sin[KM == KM_ROPE ? H * N * CSLD : 4];
-  __shared__ __attribute__((aligned(16))) float odd_raw[2 * 3 * D];                          // [image][head][q|k|v][32] of token 64
+  __shared__ __attribute__((aligned(16))) bf16 wbuf[2 * WBUF];
+  __shared__ __attribute__((aligned(16))) float s_cos_ax[CSTAB];   // [token][CSLD]; token 0 = identity
+  __shared__ __attribute__((aligned(16))) float s_sin_ax[CSTAB];
+  __shared__ __attribute__((aligned(16))) float odd_raw[2 * 3 * D];   // [image][head][q|k|v][32] of token 64
   __shared__ __attribute__((aligned(16))) bf16 wscr[12 * W32::WSCR];
   __shared__ __attribute__((aligned(16))) float s_tab[KM == KM_RELATIVE ? C::H * C::TABLD : 4];
   __shared__ __attribute__((aligned(16))) float s_coef[KM == KM_POLY ? C::PESZ : 4];
+  float* const s_cos = MIXED ? reinterpret_cast<float*>(xs_all) : s_cos_ax;
+  float* const s_sin = MIXED ? reinterpret_cast<float*>(xs_all) + H * N * CSLD : s_sin_ax;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int img = wave & 1, h = wave >> 1;       // partner waves (same head, the two images) are neighbours: they stream
-  const int b_raw = blockIdx.x * 2 + img;        // the same weight fragments at the same time
+  const int img = wave & 1, h = wave >> 1;
+  const int b_raw = blockIdx.x * 2 + img;
   const bool live = b_raw < a.B;                 // odd batch: the last workgroup's second image is a copy that stores nothing
   const int b = live ? b_raw : a.B - 1;
   const int r = lane & 31, hh = lane >> 5;
   auto stamp = [&](int slot) {
     if (CENSUS) {
       __builtin_amdgcn_sched_barrier(0);
-      if (lane == 0) a.census[((size_t)blockIdx.x * 16 + wave) * 8 + slot] = __builtin_amdgcn_s_memtime();
+      if (lane == 0) a.census[((size_t)blockIdx.x * 16 + wave) * 16 + slot] = __builtin_amdgcn_s_memtime();
       __builtin_amdgcn_sched_barrier(0);
     }
   };
   stamp(0);
+  if (CENSUS && lane == 0) a.census[((size_t)blockIdx.x * 16 + wave) * 16 + 9] = __builtin_amdgcn_s_memrealtime();
+  unsigned long long t_bar = 0, t_dma = 0;
   const bf16* const Wbase = reinterpret_cast<const bf16*>(a.wqkv);
-  const bf16* const Wh = Wbase + ((size_t)h * 3 * W32::KS * 64 + lane) * 8;              // + (mat * 12 + s) * 512
-  const bf16* const Wodd = Wbase + (size_t)3 * D * D + ((size_t)wave * 18 * 64 + lane) * 8;   // + i * 512, i < 18
-
-  // ---- the odd-token projection's 18 weight fragments (16x16x32 shape) fly under the token staging
-  bf16x8 wo[18];
+  // chunk c -> buffer buf: piece p = (head * 3 + matrix) * 2 + k-step-in-chunk, pieces wave, wave + 12, wave + 24
+  auto dma_chunk = [&](int c, int buf) {
 #pragma unroll
-  for (int i = 0; i < 18; ++i) wo[i] = *reinterpret_cast<const bf16x8*>(Wodd + (size_t)i * 512);
+    for (int i = 0; i < 3; ++i) {
+      const int p = wave + 12 * i, hm = p >> 1, sp = p & 1;
+      const bf16* src = Wbase + ((size_t)(hm * 12 + 2 * c + sp) * 64 + lane) * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(wbuf + buf * WBUF + p * 512), 16, 0, 0);
+    }
+  };
+  dma_chunk(0, 0);
 
   // ---- stage both images' tokens (LayerNorm on the way in), the PE tables
   {
@@ -163,18 +197,16 @@ __global__ __launch_bounds__(768, 3) void attn32_fwd_kernel(AttnArgs a) {
       const int row = r0 + 16 * it;
       if (row < N) *reinterpret_cast<Chunk16*>(xs_all + simg * W32::XIMG + row * LDX + cc * 8) = v[it];
     }
-    if (KM == KM_ROPE) {   // cos / sin -> LDS indexed by TOKEN; the class token's row is the identity rotation (vit.py:56-68)
-      const int ntab = (a.mode == PE_ROPE_MIXED) ? H : 1;
-      for (int q = tid; q < ntab * N * 4; q += W32::NTH) {
-        const int f4 = q & 3, row = (q >> 2) % N, t = (q >> 2) / N;
+    if (KM == KM_ROPE && !MIXED) {   // cos / sin -> LDS indexed by TOKEN; the class token's row is the identity rotation (vit.py:56-68)
+      for (int q = tid; q < N * 4; q += W32::NTH) {
+        const int f4 = q & 3, row = q >> 2;
         f32x4 cv = {1.f, 1.f, 1.f, 1.f}, sv = {0.f, 0.f, 0.f, 0.f};
         if (row >= 1) {
-          const size_t src = ((size_t)t * (N - 1) + row - 1) * 16 + 4 * f4;
-          cv = *reinterpret_cast<const f32x4*>(a.cos + src);
-          sv = *reinterpret_cast<const f32x4*>(a.sin + src);
+          cv = *reinterpret_cast<const f32x4*>(a.cos + (size_t)(row - 1) * 16 + 4 * f4);
+          sv = *reinterpret_cast<const f32x4*>(a.sin + (size_t)(row - 1) * 16 + 4 * f4);
         }
-        *reinterpret_cast<f32x4*>(&s_cos[(t * N + row) * CSLD + 4 * f4]) = cv;
-        *reinterpret_cast<f32x4*>(&s_sin[(t * N + row) * CSLD + 4 * f4]) = sv;
+        *reinterpret_cast<f32x4*>(&s_cos_ax[row * CSLD + 4 * f4]) = cv;
+        *reinterpret_cast<f32x4*>(&s_sin_ax[row * CSLD + 4 * f4]) = sv;
       }
     }
     if (KM == KM_RELATIVE) {
@@ -186,32 +218,84 @@ __global__ __launch_bounds__(768, 3) void attn32_fwd_kernel(AttnArgs a) {
     if (KM == KM_POLY) stage_poly<C>(a, 0, s_coef, N, tid, W32::NTH);
   }
   stamp(1);
-  __syncthreads();
+  __syncthreads();   // (with an LDS-DMA outstanding this is vmcnt(0) + barrier: chunk 0 has landed for everybody)
   stamp(2);
 
-  // ---- weight ring: Wv first (its latency runs under the odd-token projection)
-  bf16x8 w[12];
+  // ---- the k-loop
+  const bf16* const xr0 = xs_all + img * W32::XIMG + r * LDX + 8 * hh;   // token tile 0, k-step s: + 16 s
+  const bf16* const xr1 = xr0 + 32 * LDX;
+  const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 aV0 = z16, aV1 = z16, aK0 = z16, aK1 = z16, aQ0 = z16, aQ1 = z16;
+  // odd token (row 64 of both images; image = column & 1): feature tiles ft = 3 wave + t of the 36, flat feature 16 ft =
+  // head * 96 + {q,k,v} * 32 + 16 nt; lane (c, g) of the 16x16x32 A operand <- lane (16 nt + c) + 32 (g & 1) of the
+  // 32x32x16 fragment of k-step (g >> 1) of the chunk
+  const int oc = lane & 15, og = lane >> 4;
+  const bf16* const xodd = xs_all + (oc & 1) * W32::XIMG + 64 * LDX + 8 * og;
+  int ooff[3];
 #pragma unroll
-  for (int s = 0; s < 12; ++s) w[s] = *reinterpret_cast<const bf16x8*>(Wh + (size_t)(2 * 12 + s) * 512);
-
-  // ---- odd token (row 64 of both images): wave takes feature tiles 3 wave .. 3 wave + 2 of the 36 (flat feature
-  //      index 16 ft + ... = head * 96 + {q,k,v} * 32 + f); B operand = the two rows, image = column & 1
-  {
-    const int c = lane & 15, g = lane >> 4;
-    const bf16* xo = xs_all + (c & 1) * W32::XIMG + 64 * LDX + 8 * g;
-    Frag<bf16> xf[6];
-#pragma unroll
-    for (int ks = 0; ks < 6; ++ks) xf[ks].v = ldsfrag(xo + 32 * ks);
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 6; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo[t * 6 + ks], xf[ks].v, acc, 0, 0, 0);
-      if (c < 2) *reinterpret_cast<f32x4*>(&odd_raw[c * 3 * D + 16 * (3 * wave + t) + 4 * g]) = acc;
-    }
+  for (int t = 0; t < 3; ++t) {
+    const int ft = 3 * wave + t, hm = ft >> 1, nt = ft & 1;
+    ooff[t] = (hm * 2 + (og >> 1)) * 512 + ((16 * nt + oc) + 32 * (og & 1)) * 8;
   }
-  __syncthreads();
-  const int cs_tab = (KM == KM_ROPE && a.mode == PE_ROPE_MIXED) ? h * N * CSLD : 0;
+  f32x4 od[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const int woff = (h * 3) * 2 * 512 + lane * 8;   // this head's q fragment of k-step 0 of a chunk; k: + 2 * 512, v: + 4 * 512
+#pragma unroll 1
+  for (int c = 0; c < 6; ++c) {
+    if (c + 1 < 6) dma_chunk(c + 1, (c + 1) & 1);
+    const bf16* const wb = wbuf + (c & 1) * WBUF;
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+      const bf16x8 xa = ldsfrag(xr0 + 32 * c + 16 * sp), xb = ldsfrag(xr1 + 32 * c + 16 * sp);
+      const bf16x8 wq = ldsfrag(wb + woff + (0 + sp) * 512), wk = ldsfrag(wb + woff + (2 + sp) * 512),
+                   wv = ldsfrag(wb + woff + (4 + sp) * 512);
+      mma32(xa, wv, aV0);
+      mma32(xb, wv, aV1);
+      mma32(wk, xa, aK0);
+      mma32(wk, xb, aK1);
+      mma32(wq, xa, aQ0);
+      mma32(wq, xb, aQ1);
+    }
+    {
+      const bf16x8 xo = ldsfrag(xodd + 32 * c);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) od[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ldsfrag(wb + ooff[t]), xo, od[t], 0, 0, 0);
+    }
+    if (c == 5 && oc < 2) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t) *reinterpret_cast<f32x4*>(&odd_raw[oc * 3 * D + 16 * (3 * wave + t) + 4 * og]) = od[t];
+    }
+    if (CENSUS) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+      __syncthreads();
+      t_bar += __builtin_amdgcn_s_memtime() - t1;
+      t_dma += t1 - t0;
+      __builtin_amdgcn_sched_barrier(0);
+    } else
+    __syncthreads();   // chunk c + 1 landed (vmcnt(0) before the barrier); everybody is done with buffer c & 1
+  }
+  stamp(3);
+
+  // ---- v: acc[rho] = v[token 32 t + perm(rho, hh)][feature r] -> V^T operand fragments
+  bf16x8 vf[4];
+  vf[0] = pack8<0>(aV0); vf[1] = pack8<1>(aV0); vf[2] = pack8<0>(aV1); vf[3] = pack8<1>(aV1);
+  if (MIXED) {   // per-head tables -> the token region (free now), indexed by token like the axial table
+    for (int q = tid; q < H * N * 4; q += W32::NTH) {
+      const int f4 = q & 3, row = (q >> 2) % N, t = (q >> 2) / N;
+      f32x4 cv = {1.f, 1.f, 1.f, 1.f}, sv = {0.f, 0.f, 0.f, 0.f};
+      if (row >= 1) {
+        const size_t src = ((size_t)t * (N - 1) + row - 1) * 16 + 4 * f4;
+        cv = *reinterpret_cast<const f32x4*>(a.cos + src);
+        sv = *reinterpret_cast<const f32x4*>(a.sin + src);
+      }
+      *reinterpret_cast<f32x4*>(&s_cos[(t * N + row) * CSLD + 4 * f4]) = cv;
+      *reinterpret_cast<f32x4*>(&s_sin[(t * N + row) * CSLD + 4 * f4]) = sv;
+    }
+    __syncthreads();
+  }
+  const int cs_tab = MIXED ? h * N * CSLD : 0;
   bf16* const ws = wscr + wave * W32::WSCR;
   {  // rotate the odd token's q and k (token 64 = grid position 63), park q | k | v as bf16 in this wave's scratch
     const float* raw = odd_raw + img * 3 * D + h * 96;
@@ -227,28 +311,8 @@ __global__ __launch_bounds__(768, 3) void attn32_fwd_kernel(AttnArgs a) {
     ws[m * 32 + f] = (bf16)val;
     if (lane < 32) ws[64 + lane] = (bf16)raw[64 + lane];
   }
-  stamp(3);
 
-  const bf16* const xr0 = xs_all + img * W32::XIMG + r * LDX + 8 * hh;   // token tile 0, k-step s: + 16 s
-  const bf16* const xr1 = xr0 + 32 * LDX;
-  const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-  // ---- v, un-swapped: acc[rho] = v[token 32 t + perm(rho, hh)][feature r] -> V^T operand fragments
-  bf16x8 vf[4];
-  {
-    f32x16 a0 = z16, a1 = z16;
-#pragma unroll
-    for (int s = 0; s < 12; ++s) {
-      const bf16x8 xa = ldsfrag(xr0 + 16 * s), xb = ldsfrag(xr1 + 16 * s);
-      mma32(xa, w[s], a0);
-      mma32(xb, w[s], a1);
-      w[s] = *reinterpret_cast<const bf16x8*>(Wh + (size_t)(1 * 12 + s) * 512);   // Wk's k-step s takes the ring slot
-    }
-    vf[0] = pack8<0>(a0); vf[1] = pack8<1>(a0); vf[2] = pack8<0>(a1); vf[3] = pack8<1>(a1);
-  }
-  stamp(4);
-
-  // ---- k and q, swapped: acc[rho] = k[token 32 t + r][feature perm(rho, hh)]; rotate; -> fragments
+  // ---- k and q: acc[rho] = k[token 32 t + r][feature perm(rho, hh)]; rotate; -> fragments
   auto rope = [&](f32x16& acc, int tile) {
     if (KM == KM_ROPE) {
       const int tok = 32 * tile + r;
@@ -266,33 +330,13 @@ __global__ __launch_bounds__(768, 3) void attn32_fwd_kernel(AttnArgs a) {
     }
   };
   bf16x8 kf[2][2], qf[2][2];
-  {
-    f32x16 a0 = z16, a1 = z16;
-#pragma unroll
-    for (int s = 0; s < 12; ++s) {
-      const bf16x8 xa = ldsfrag(xr0 + 16 * s), xb = ldsfrag(xr1 + 16 * s);
-      mma32(w[s], xa, a0);
-      mma32(w[s], xb, a1);
-      w[s] = *reinterpret_cast<const bf16x8*>(Wh + (size_t)(0 * 12 + s) * 512);   // Wq
-    }
-    rope(a0, 0);
-    rope(a1, 1);
-    kf[0][0] = pack8<0>(a0); kf[0][1] = pack8<1>(a0); kf[1][0] = pack8<0>(a1); kf[1][1] = pack8<1>(a1);
-  }
-  stamp(5);
-  {
-    f32x16 a0 = z16, a1 = z16;
-#pragma unroll
-    for (int s = 0; s < 12; ++s) {
-      const bf16x8 xa = ldsfrag(xr0 + 16 * s), xb = ldsfrag(xr1 + 16 * s);
-      mma32(w[s], xa, a0);
-      mma32(w[s], xb, a1);
-    }
-    rope(a0, 0);
-    rope(a1, 1);
-    qf[0][0] = pack8<0>(a0); qf[0][1] = pack8<1>(a0); qf[1][0] = pack8<0>(a1); qf[1][1] = pack8<1>(a1);
-  }
-  stamp(6);
+  rope(aK0, 0);
+  rope(aK1, 1);
+  kf[0][0] = pack8<0>(aK0); kf[0][1] = pack8<1>(aK0); kf[1][0] = pack8<0>(aK1); kf[1][1] = pack8<1>(aK1);
+  rope(aQ0, 0);
+  rope(aQ1, 1);
+  qf[0][0] = pack8<0>(aQ0); qf[0][1] = pack8<1>(aQ0); qf[1][0] = pack8<0>(aQ1); qf[1][1] = pack8<1>(aQ1);
+  stamp(4);
 
   // ---- the odd token's operand fragments from the wave scratch: position (hh, j) <-> feature 16 s + 4 hh + (j & 3) + 8 (j >> 2)
   auto odd_rows = [&](int base, bf16x8 (&f)[2]) {   // every row (A operand) / column (B operand) = the odd token's vector
@@ -356,7 +400,7 @@ __global__ __launch_bounds__(768, 3) void attn32_fwd_kernel(AttnArgs a) {
     }
     float m = sodd;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) m = fmaxf(m, fmaxf(s0[q], s1[q]));
+    for (int q = 0; q < 16; ++q) m = max3(m, s0[q], s1[q]);
     m = swap32_max(m);
     float l = 0.f;
 #pragma unroll
@@ -379,6 +423,7 @@ __global__ __launch_bounds__(768, 3) void attn32_fwd_kernel(AttnArgs a) {
     mma32(vfo, pfo, o);
     store_rows(o, __builtin_amdgcn_rcpf(l), i, live);
   }
+  stamp(5);
 
   // ---- the odd token as a query: logits with the KEY on the lane (A = q_odd in every row, B = K^T), softmax by a
   //      32-lane reduction, P through the wave scratch into the B-operand order, O^T row stored from lanes 0 and 32
@@ -399,7 +444,7 @@ __global__ __launch_bounds__(768, 3) void attn32_fwd_kernel(AttnArgs a) {
       a1 += pe_bias2<C, KM>(a, s_tab, s_coef, h, 64, 32 + r, N);
       a2 += pe_bias2<C, KM>(a, s_tab, s_coef, h, 64, 64, N);
     }
-    const float m = half_max(fmaxf(fmaxf(a0, a1), a2));
+    const float m = half_max(max3(a0, a1, a2));
     const float p0 = __builtin_amdgcn_exp2f(a0 - m), p1 = __builtin_amdgcn_exp2f(a1 - m), p2 = __builtin_amdgcn_exp2f(a2 - m);
     const float l = half_sum(p0 + p1) + p2;
     bf16* const pr = ws + 128;
@@ -424,39 +469,30 @@ __global__ __launch_bounds__(768, 3) void attn32_fwd_kernel(AttnArgs a) {
     mma32(vfo, pfo, o);
     store_rows(o, __builtin_amdgcn_rcpf(l), 64, live && r == 0);
   }
-  stamp(7);
+  stamp(6);
+  if (CENSUS && lane == 0) {
+    a.census[((size_t)blockIdx.x * 16 + wave) * 16 + 8] = t_bar;
+    a.census[((size_t)blockIdx.x * 16 + wave) * 16 + 11] = t_dma;
+    a.census[((size_t)blockIdx.x * 16 + wave) * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 // ---- the wide pack ------------------------------------------------------------------------------------------------
-// section 0 [3 D D elements]: block ((h * 3 + mat) * 12 + s) = 64 lanes x 8: lane (r = l & 31, hh = l >> 5), element j =
-//   W[mat D + 32 h + r][16 s + 8 hh + j]                       (32x32x16 operand fragments)
-// section 1 [3 D D elements]: block ((h * 3 + mat) * 2 + nt) * 6 + ks: lane (c = l & 15, g = l >> 4), element e =
-//   W[mat D + 32 h + 16 nt + c][32 ks + 8 g + e]               (16x16x32 fragments of the odd-token projection)
-// both with the q rows (mat 0) multiplied by qscale = hd^-0.5 * log2(e)
+// 3 D D elements: block ((h * 3 + mat) * (D / 16) + s) = 64 lanes x 8: lane (r = l & 31, hh = l >> 5), element j =
+//   W[mat D + 32 h + r][16 s + 8 hh + j]                       (32x32x16 operand fragments, 1 KB each)
+// with the q rows (mat 0) multiplied by qscale = hd^-0.5 * log2(e)
 VITPE_DEV void wide_src(long long idx, int D, int& row, int& col, int& mat) {
-  const long long sec = idx / ((long long)3 * D * D);
-  long long t = idx % ((long long)3 * D * D);
-  const int e = (int)(t & 7), l = (int)((t >> 3) & 63);
-  long long blk = t >> 9;
-  if (sec == 0) {
-    const int S = D / 16;
-    const int s = (int)(blk % S); blk /= S;
-    mat = (int)(blk % 3);
-    const int h = (int)(blk / 3);
-    row = mat * D + 32 * h + (l & 31);
-    col = 16 * s + 8 * (l >> 5) + e;
-  } else {
-    const int KS = D / 32;
-    const int ks = (int)(blk % KS); blk /= KS;
-    const int nt = (int)(blk % 2); blk /= 2;
-    mat = (int)(blk % 3);
-    const int h = (int)(blk / 3);
-    row = mat * D + 32 * h + 16 * nt + (l & 15);
-    col = 32 * ks + 8 * (l >> 4) + e;
-  }
+  const int e = (int)(idx & 7), l = (int)((idx >> 3) & 63);
+  long long blk = idx >> 9;
+  const int S = D / 16;
+  const int s = (int)(blk % S); blk /= S;
+  mat = (int)(blk % 3);
+  const int h = (int)(blk / 3);
+  row = mat * D + 32 * h + (l & 31);
+  col = 16 * s + 8 * (l >> 5) + e;
 }
 __global__ void pack_qkv_wide_kernel(const float* __restrict__ w, bf16* __restrict__ dst, int D, float qscale) {
-  const long long total = (long long)6 * D * D;
+  const long long total = (long long)3 * D * D;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     int row, col, mat;
     wide_src(idx, D, row, col, mat);
@@ -472,22 +508,22 @@ extern "C" int vitpe_fused_attention_wide_supported(int dtype, int N, int D, int
   return dtype == 1 && N == 65 && D == 192 && HD == 32;
 }
 
-extern "C" int vitpe_qkv_wide_pack_elems(int D) { return 6 * D * D; }
+extern "C" int vitpe_qkv_wide_pack_elems(int D) { return 3 * D * D; }
 
 extern "C" int vitpe_pack_qkv_weights_wide(int dtype, const float* wqkv, void* packed, int D, int HD, hipStream_t stream) {
   VITPE_REQUIRE(wqkv && packed && dtype == 1 && HD == 32 && D > 0 && D % 32 == 0);
-  const long long total = (long long)6 * D * D;
+  const long long total = (long long)3 * D * D;
   const unsigned blocks = (unsigned)min((total + 255) / 256, (long long)2048);
   hipLaunchKernelGGL(pack_qkv_wide_kernel, dim3(blocks), dim3(256), 0, stream, wqkv, (bf16*)packed, D,
                      LOG2E / sqrtf((float)HD));
   VITPE_CHECK_LAUNCH();
 }
 
-template <int KM>
+template <int KM, bool MIXED = false>
 static int launch_wide(const AttnArgs& a, hipStream_t s) {
   const dim3 grid((a.B + 1) / 2), block(768);
-  if (a.ln_gamma != nullptr) hipLaunchKernelGGL((attn32_fwd_kernel<KM, true>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((attn32_fwd_kernel<KM, false>), grid, block, 0, s, a);
+  if (a.ln_gamma != nullptr) hipLaunchKernelGGL((attn32_fwd_kernel<KM, true, MIXED>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((attn32_fwd_kernel<KM, false, MIXED>), grid, block, 0, s, a);
   VITPE_CHECK_LAUNCH();
 }
 
@@ -515,20 +551,21 @@ extern "C" int vitpe_fused_attention_fwd_wide(int dtype, const void* x, const fl
   switch (mode) {
     case PE_RELATIVE: return launch_wide<KM_RELATIVE>(a, stream);
     case PE_POLY: return launch_wide<KM_POLY>(a, stream);
-    case PE_ROPE_AXIAL:
-    case PE_ROPE_MIXED: return launch_wide<KM_ROPE>(a, stream);
+    case PE_ROPE_AXIAL: return launch_wide<KM_ROPE>(a, stream);
+    case PE_ROPE_MIXED: return launch_wide<KM_ROPE, true>(a, stream);
     default: return launch_wide<KM_PLAIN>(a, stream);
   }
 }
 
-// debug: phase census of the wide forward (rope-axial, no LayerNorm): census[(workgroup * 16 + wave) * 8 + slot] =
-// s_memtime at 0 start, 1 staged, 2 barrier passed, 3 odd token projected + exchanged, 4 v, 5 k, 6 q, 7 end
+// debug: phase census of the wide forward (rope-axial, no LayerNorm): census[(workgroup * 16 + wave) * 16 + slot] =
+// s_memtime at 0 start, 1 staged, 2 barrier passed, 3 k-loop done, 4 operand fragments built, 5 patch queries done, 6 end;
+// 8 = cycles inside the k-loop's barriers (incl. the LDS-DMA wait), 9 / 10 = s_memrealtime (100 MHz, chip-wide) at start / end
 extern "C" int vitpe_debug_attn32_census(const void* xn, const void* wqkv_wide, void* out, const float* cos,
                                          const float* sin, int B, unsigned long long* census, hipStream_t stream) {
   VITPE_REQUIRE(xn && wqkv_wide && out && cos && sin && census && B > 0);
   AttnArgs a{};
   a.xn = xn; a.wqkv = wqkv_wide; a.out = out; a.cos = cos; a.sin = sin; a.B = B; a.N = 65; a.mode = PE_ROPE_AXIAL; a.grid = 8;
   a.scale = 0.17677669f; a.census = census;
-  hipLaunchKernelGGL((attn32_fwd_kernel<KM_ROPE, false, true>), dim3((B + 1) / 2), dim3(768), 0, stream, a);
+  hipLaunchKernelGGL((attn32_fwd_kernel<KM_ROPE, false, false, true>), dim3((B + 1) / 2), dim3(768), 0, stream, a);
   VITPE_CHECK_LAUNCH();
 }

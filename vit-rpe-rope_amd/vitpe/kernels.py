@@ -440,7 +440,7 @@ def fused_attention_wide_supported(dtype, N, D, HD) -> bool:
 
 
 def pack_qkv_weights_wide(wqkv_f32, dtype, num_heads, out=None):
-    """fp32 master [3D,D] -> the wide pack of the 32x32-tile forward kernel (include/vitpe.h: 6 D D elements, q rows
+    """fp32 master [3D,D] -> the wide pack of the 32x32-tile forward kernel (include/vitpe.h: 3 D D elements, q rows
     pre-multiplied by hd^-0.5 log2 e)."""
     require_device(wqkv_f32, out)
     _f32(wqkv_f32, "wqkv")
@@ -458,7 +458,7 @@ def fused_attention_fwd_wide(xn, wqkv_wide, num_heads, pe: PETables, out=None, l
     require_device(xn, wqkv_wide, pe.cos, pe.sin, pe.table, pe.coeff, out, xn_out)
     B, N, D = xn.shape
     HD = D // num_heads
-    assert wqkv_wide.numel() == 6 * D * D and wqkv_wide.dtype == xn.dtype
+    assert wqkv_wide.numel() == 3 * D * D and wqkv_wide.dtype == xn.dtype
     o = out if out is not None else torch.empty_like(xn)
     g = ln if ln is not None else (None, None, None, None)
     if ln is not None:
