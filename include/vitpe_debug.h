@@ -25,9 +25,10 @@ int vitpe_debug_attn_census(const void* xn, const void* wqkv, void* out, const f
                             int B, unsigned long long* census, vitpe_stream_t stream);
 /* the same for the wide forward (csrc/attn32.hip; wqkv_wide = vitpe_pack_qkv_weights_wide): 16 slots per wave: 0 start,
  * 1 staged, 2 barrier passed, 3 projection k-loop done, 4 operand fragments built, 5 patch queries done, 6 end, 8 cycles in
- * the k-loop's barriers, 9 / 10 s_memrealtime (100 MHz) at start / end                                       */
+ * the k-loop's barriers, 9 / 10 s_memrealtime (100 MHz) at start / end, 11 cycles waiting for the own LDS-DMA pieces; exp: timing experiments with
+ * WRONG results (1 no 65th-token work in the k-loop, 2 no k-loop barriers), 0 = the real kernel                                       */
 int vitpe_debug_attn32_census(const void* xn, const void* wqkv_wide, void* out, const float* cos, const float* sin,
-                              int B, unsigned long long* census, vitpe_stream_t stream);
+                              int B, unsigned long long* census, int exp, vitpe_stream_t stream);
 /* phase census of the second-generation block tail (training instantiation with stamps; bf16, D = 192):
  * census[(workgroup * 9 + wave) * 16 + slot] = s_memtime at 0 start, 1 first slab landed, 2 proj product done,
  * 3 LayerNorm2 epilogue done, 4 period-0 barrier passed, 5 period 0 done, 6 periods 1.. done, 7 last barrier passed,

@@ -98,26 +98,32 @@ VITPE_DEV float swap32_sum(float v) {
 // KM: positional-encoding class (attn_common.h); LNF: LayerNorm fused into the staging; MIXED: per-head cos / sin
 // tables (rope-mixed); CENSUS: debug stamps
 //
-// Projection = one workgroup-synchronous k-loop over six 32-deep chunks.  Chunk c of EVERY head's Wq / Wk / Wv (36 1-KB
-// fragments) is brought into LDS once per workgroup by LDS-DMA (three pieces per wave, a chunk ahead, two buffers);
-// a wave reads, per 16-deep k-step, two token fragments and its head's three weight fragments and issues six MFMAs into
-// SIX live accumulators (v, k, q of both token tiles: 96 registers): every operand byte is read from LDS exactly once
-// and every weight byte leaves L2 once per workgroup (the register-ring version fetched 648 KB per CU from L2 -- each
-// wave its own copy -- and its projection phases ran at the L2 -> CU rate, census in DESIGN.md).  The odd token's
-// 16x16x32 operands are gathered from the same LDS image (a 16x16x32 fragment is a different lane -> address map of two
-// consecutive 32x32x16 fragments), three feature tiles per wave and chunk.
-template <int KM, bool LNF, bool MIXED, bool CENSUS = false>
+// Projection = a k-loop over six 32-deep chunks, synchronised PER HEAD.  The two waves of a head (its two images) share
+// a private double-buffered ring of that head's Wq / Wk / Wv chunk (6 1-KB fragments per chunk, filled by LDS-DMA: three
+// pieces per wave, a chunk ahead; every weight byte leaves L2 once per workgroup -- the register-ring version fetched
+// 648 KB per CU from L2, each wave its own copy, and ran at the L2 -> CU rate).  Per 16-deep k-step a wave reads two token
+// fragments and its head's three weight fragments and issues six MFMAs into SIX live accumulators (v, k, q of both token
+// tiles: 96 registers): every operand byte is read from LDS exactly once.  The odd token's 16x16x32 operands are
+// gathered from the same LDS image (a 16x16x32 fragment is a different lane -> address map of two consecutive 32x32x16
+// fragments): the pair projects the odd tokens of BOTH images for its head, wave i the 16-feature tile i of q, k, v.
+// Synchronisation after the staging barrier is a two-wave handshake per chunk (an LDS counter per head and chunk: "my
+// reads of chunk c are done and my pieces of chunk c + 1 have landed"): no workgroup barrier, so the three waves of a
+// SIMD drift apart and one's LDS waits and softmax run under another's MFMAs (with s_barrier per chunk the oldest wave
+// of a SIMD spent 6 K of its 14 K k-loop cycles parked: census in DESIGN.md).  The LDS-DMA is issued from inline asm:
+// through the builtin, hipcc waits vmcnt(0) right behind the issue (it cannot tell the ring slots apart).
+template <int KM, bool LNF, bool MIXED, bool CENSUS = false, int EXP = 0>   // EXP: timing experiments of the census build (WRONG results)
 __global__ __launch_bounds__(768, 3) void attn32_fwd_kernel(AttnArgs a) {
   using C = AttnCfg<bf16, 32, 192, 5, 1, 65>;   // (bias-table helpers of attn_common.h: TABLD = 160, PBLD = 32)
   constexpr int D = W32::D, N = W32::N, LDX = W32::LDX, H = W32::H;
   constexpr int CSLD = MIXED ? 16 : W32::CSLD;   // (mixed: unpadded rows, or the six tables would not fit the token region)
-  constexpr int NPIECE = 36, WBUF = NPIECE * 512;   // one chunk: (head, matrix, k-step in chunk) x 1 KB
+  constexpr int PBUF = 6 * 512, HBUF = 2 * PBUF;   // a head's ring: 2 buffers x (matrix, k-step in chunk) x 1 KB
   // rope-mixed: the per-head tables (62 KB) do not fit beside the weight ring; they are staged into the token region
   // once the projections are done with it
   constexpr int CSTAB = (KM != KM_ROPE) ? 4 : (MIXED ? 4 : N * CSLD);
   static_assert(!MIXED || H * N * CSLD * 4 * 2 <= 2 * W32::XIMG * 2, "mixed tables must fit the token region");
   __shared__ __attribute__((aligned(16))) bf16 xs_all[2 * W32::XIMG];
-  __shared__ __attribute__((aligned(16))) bf16 wbuf[2 * WBUF];
+  __shared__ __attribute__((aligned(16))) bf16 wbuf[H * HBUF];
+  __shared__ int pflag[H * 8];   // [head][handshake]: arrivals (2 = both waves)
   __shared__ __attribute__((aligned(16))) float s_cos_ax[CSTAB];   // [token][CSLD]; token 0 = identity
   __shared__ __attribute__((aligned(16))) float s_sin_ax[CSTAB];
   __shared__ __attribute__((aligned(16))) float odd_raw[2 * 3 * D];   // [image][head][q|k|v][32] of token 64
@@ -145,57 +151,68 @@ __global__ __launch_bounds__(768, 3) void attn32_fwd_kernel(AttnArgs a) {
   if (CENSUS && lane == 0) a.census[((size_t)blockIdx.x * 16 + wave) * 16 + 9] = __builtin_amdgcn_s_memrealtime();
   unsigned long long t_bar = 0, t_dma = 0;
   const bf16* const Wbase = reinterpret_cast<const bf16*>(a.wqkv);
-  // chunk c -> buffer buf: piece p = (head * 3 + matrix) * 2 + k-step-in-chunk, pieces wave, wave + 12, wave + 24
+  // chunk c of this head -> ring buffer buf: piece p = matrix * 2 + k-step-in-chunk; this wave issues p = 3 img .. + 2
+  const unsigned ring_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(wbuf + h * HBUF);
+  const unsigned lane16 = lane * 16;
   auto dma_chunk = [&](int c, int buf) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const int p = wave + 12 * i, hm = p >> 1, sp = p & 1;
-      const bf16* src = Wbase + ((size_t)(hm * 12 + 2 * c + sp) * 64 + lane) * 8;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(wbuf + buf * WBUF + p * 512), 16, 0, 0);
+      const int p = 3 * img + i, mat = p >> 1, sp = p & 1;
+      const bf16* src = Wbase + (size_t)((h * 3 + mat) * 12 + 2 * c + sp) * 512;        // wave-uniform
+      const unsigned dst = ring_lds + (unsigned)(buf * PBUF + p * 512) * 2;              // LDS byte address, wave-uniform
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(lane16), "s"(dst), "s"(src) : "memory");
     }
   };
+  if (tid < H * 8) pflag[tid] = 0;
   dma_chunk(0, 0);
+  dma_chunk(1, 1);
 
   // ---- stage both images' tokens (LayerNorm on the way in), the PE tables
   {
+    // the workgroup's two images are 130 consecutive rows: one wave-uniform base, 32-bit per-thread offsets (the
+    // per-image base pointers of the first version cost 64-bit address arithmetic per load: a third of this phase's VALU)
     const int simg = tid / 384, st = tid % 384, cc = st % 24, r0 = st / 24;
-    const int sb_raw = blockIdx.x * 2 + simg;
-    const bool slive = sb_raw < a.B;
-    const int sb = slive ? sb_raw : a.B - 1;
-    const bf16* xg = reinterpret_cast<const bf16*>(a.xn) + (size_t)sb * N * D + cc * 8;
+    const bool slive = blockIdx.x * 2 + simg < a.B;
+    const int srow = slive ? simg * N : 0;                       // odd batch: the idle second slot re-reads image 0
+    const bf16* const xbase = reinterpret_cast<const bf16*>(a.xn) + (size_t)blockIdx.x * 2 * N * D;
+    const float* const mbase = LNF ? a.ln_mean + (size_t)blockIdx.x * 2 * N : nullptr;
+    const float* const rbase = LNF ? a.ln_rstd + (size_t)blockIdx.x * 2 * N : nullptr;
     Chunk16 v[5];
     float mu[5], rs[5];
 #pragma unroll
     for (int it = 0; it < 5; ++it) {
-      const int rowc = min(r0 + 16 * it, N - 1);
-      v[it] = *reinterpret_cast<const Chunk16*>(xg + (size_t)rowc * D);
-      mu[it] = LNF ? a.ln_mean[(size_t)sb * N + rowc] : 0.f;
-      rs[it] = LNF ? a.ln_rstd[(size_t)sb * N + rowc] : 0.f;
+      const unsigned rowg = (unsigned)(srow + min(r0 + 16 * it, N - 1));
+      v[it] = *reinterpret_cast<const Chunk16*>(xbase + rowg * (unsigned)D + (unsigned)(cc * 8));
+      mu[it] = LNF ? mbase[rowg] : 0.f;
+      rs[it] = LNF ? rbase[rowg] : 0.f;
     }
     if (LNF) {
       float gq[8], bq[8];
+      {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.ln_gamma + cc * 8), g1 = *reinterpret_cast<const f32x4*>(a.ln_gamma + cc * 8 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.ln_beta + cc * 8), b1 = *reinterpret_cast<const f32x4*>(a.ln_beta + cc * 8 + 4);
 #pragma unroll
-      for (int t = 0; t < 8; ++t) { gq[t] = a.ln_gamma[cc * 8 + t]; bq[t] = a.ln_beta[cc * 8 + t]; }
-      bf16* xo = (a.xn_out != nullptr && slive) ? reinterpret_cast<bf16*>(a.xn_out) + (size_t)sb * N * D + cc * 8 : nullptr;
+        for (int t = 0; t < 4; ++t) { gq[t] = g0[t]; gq[4 + t] = g1[t]; bq[t] = b0[t]; bq[4 + t] = b1[t]; }
+      }
 #pragma unroll
       for (int it = 0; it < 5; ++it) {
         const int row = r0 + 16 * it;
-        if (row < N) {
+        if (it < 4 || row < N) {
           float f[8];
           chunk_to_f32<bf16>(v[it], f);
           const float sc = rs[it], sh = -mu[it] * rs[it];
 #pragma unroll
           for (int t = 0; t < 8; ++t) f[t] = fmaf(fmaf(f[t], sc, sh), gq[t], bq[t]);
           v[it] = f32_to_chunk<bf16>(f);
-          if (xo != nullptr) __builtin_nontemporal_store(v[it], reinterpret_cast<Chunk16*>(xo + (size_t)row * D));   // read again only in backward
         }
       }
     }
 #pragma unroll
     for (int it = 0; it < 5; ++it) {
       const int row = r0 + 16 * it;
-      if (row < N) *reinterpret_cast<Chunk16*>(xs_all + simg * W32::XIMG + row * LDX + cc * 8) = v[it];
+      if (it < 4 || row < N) *reinterpret_cast<Chunk16*>(xs_all + simg * W32::XIMG + row * LDX + cc * 8) = v[it];
     }
     if (KM == KM_ROPE && !MIXED) {   // cos / sin -> LDS indexed by TOKEN; the class token's row is the identity rotation (vit.py:56-68)
       for (int q = tid; q < N * 4; q += W32::NTH) {
@@ -218,7 +235,8 @@ __global__ __launch_bounds__(768, 3) void attn32_fwd_kernel(AttnArgs a) {
     if (KM == KM_POLY) stage_poly<C>(a, 0, s_coef, N, tid, W32::NTH);
   }
   stamp(1);
-  __syncthreads();   // (with an LDS-DMA outstanding this is vmcnt(0) + barrier: chunk 0 has landed for everybody)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the six LDS-DMA pieces of chunks 0 and 1 (hipcc does not count them)
+  __syncthreads();
   stamp(2);
 
   // ---- the k-loop
@@ -226,62 +244,131 @@ __global__ __launch_bounds__(768, 3) void attn32_fwd_kernel(AttnArgs a) {
   const bf16* const xr1 = xr0 + 32 * LDX;
   const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   f32x16 aV0 = z16, aV1 = z16, aK0 = z16, aK1 = z16, aQ0 = z16, aQ1 = z16;
-  // odd token (row 64 of both images; image = column & 1): feature tiles ft = 3 wave + t of the 36, flat feature 16 ft =
-  // head * 96 + {q,k,v} * 32 + 16 nt; lane (c, g) of the 16x16x32 A operand <- lane (16 nt + c) + 32 (g & 1) of the
-  // 32x32x16 fragment of k-step (g >> 1) of the chunk
+  // odd token (row 64 of both images; image = column & 1): this wave's feature tiles are nt = img of q, k, v of its head
+  // (flat feature 16 ft = head * 96 + {q,k,v} * 32 + 16 nt); lane (c, g) of the 16x16x32 A operand <- lane
+  // (16 nt + c) + 32 (g & 1) of the 32x32x16 fragment of k-step (g >> 1) of the chunk
   const int oc = lane & 15, og = lane >> 4;
   const bf16* const xodd = xs_all + (oc & 1) * W32::XIMG + 64 * LDX + 8 * og;
   int ooff[3];
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
-    const int ft = 3 * wave + t, hm = ft >> 1, nt = ft & 1;
-    ooff[t] = (hm * 2 + (og >> 1)) * 512 + ((16 * nt + oc) + 32 * (og & 1)) * 8;
+    ooff[t] = h * HBUF + (t * 2 + (og >> 1)) * 512 + ((16 * img + oc) + 32 * (og & 1)) * 8;
   }
   f32x4 od[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  const int woff = (h * 3) * 2 * 512 + lane * 8;   // this head's q fragment of k-step 0 of a chunk; k: + 2 * 512, v: + 4 * 512
-#pragma unroll 1
-  for (int c = 0; c < 6; ++c) {
-    if (c + 1 < 6) dma_chunk(c + 1, (c + 1) & 1);
-    const bf16* const wb = wbuf + (c & 1) * WBUF;
-#pragma unroll
-    for (int sp = 0; sp < 2; ++sp) {
-      const bf16x8 xa = ldsfrag(xr0 + 32 * c + 16 * sp), xb = ldsfrag(xr1 + 32 * c + 16 * sp);
-      const bf16x8 wq = ldsfrag(wb + woff + (0 + sp) * 512), wk = ldsfrag(wb + woff + (2 + sp) * 512),
-                   wv = ldsfrag(wb + woff + (4 + sp) * 512);
-      mma32(xa, wv, aV0);
-      mma32(xb, wv, aV1);
-      mma32(wk, xa, aK0);
-      mma32(wk, xb, aK1);
-      mma32(wq, xa, aQ0);
-      mma32(wq, xb, aQ1);
+  // Rolling prefetch: every LDS read is issued two MFMAs (>= 64 matrix-pipe cycles of this wave, ~200 with its two SIMD
+  // partners) ahead of its first use, never more than ~8 fragments in flight (the six accumulators leave no room for a
+  // whole k-step of double buffering).  Order per k-step: v (needs x, Wv), k (Wk), q (Wq); the next k-step's x / Wv / Wk
+  // are requested under them.  The next chunk's token fragments (static data) are requested BEFORE the barrier, its
+  // weight fragments right after it.  Two chunks per loop iteration: every LDS address is base + immediate.
+  const bf16* const wp = wbuf + h * HBUF + lane * 8;            // buffer 0, this head's q fragment of k-step 0; k: + 2 * 512, v: + 4 * 512
+  const bf16* xp = xr0;                                          // k-step 0 of the current chunk pair
+  const bf16* xop = xodd;
+  // two-wave handshake k of this head: own LDS reads done + own LDS-DMA pieces landed, then wait for the partner
+  auto pair_sync = [&](int k) {
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t0 = 0;
+    if (CENSUS) t0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (EXP & 4) {
+      __builtin_amdgcn_s_barrier();
+    } else if (!(EXP & 2)) {
+      typedef __attribute__((address_space(3))) int lds_int;
+      lds_int* const ctr = (lds_int*)(pflag + h * 8 + k);
+      int seen = 0;
+      if (lane == 0) seen = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // 1: the partner is already here
+      seen = __builtin_amdgcn_readfirstlane(seen);
+      for (int spin = 0; seen < 1 && spin < (1 << 18); ++spin) {        // (bounded: a lost partner must not hang the chip)
+        __builtin_amdgcn_s_sleep(1);
+        seen = __builtin_amdgcn_readfirstlane(*(volatile lds_int*)ctr) - 1;
+      }
     }
-    {
-      const bf16x8 xo = ldsfrag(xodd + 32 * c);
-#pragma unroll
-      for (int t = 0; t < 3; ++t) od[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ldsfrag(wb + ooff[t]), xo, od[t], 0, 0, 0);
-    }
-    if (c == 5 && oc < 2) {
-#pragma unroll
-      for (int t = 0; t < 3; ++t) *reinterpret_cast<f32x4*>(&odd_raw[oc * 3 * D + 16 * (3 * wave + t) + 4 * og]) = od[t];
-    }
-    if (CENSUS) {
-      __builtin_amdgcn_sched_barrier(0);
-      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-      __syncthreads();
-      t_bar += __builtin_amdgcn_s_memtime() - t1;
-      t_dma += t1 - t0;
-      __builtin_amdgcn_sched_barrier(0);
-    } else
-    __syncthreads();   // chunk c + 1 landed (vmcnt(0) before the barrier); everybody is done with buffer c & 1
+    asm volatile("" ::: "memory");
+    if (CENSUS) t_bar += __builtin_amdgcn_s_memtime() - t0;
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // One k-step of double buffering: the five fragments of k-step j + 1 are requested before the six MFMAs of k-step j
+  // (a wave alone on the matrix pipe then covers ~190 cycles of LDS latency; two MFMAs of lead, the first version,
+  // left the oldest wave of a SIMD at a third of the pipe rate).  The handshake of chunk c sits between its two k-steps:
+  // all reads of chunk c are issued (and waited for) by then, so the pieces of chunk c + 2 may overwrite its buffer one
+  // whole chunk before they are needed, and chunk c + 1 -- requested at the previous handshake -- has landed.
+#define VITPE_A32_FENCE __builtin_amdgcn_sched_barrier(0);
+#define VITPE_A32_MMA6(XA, XB, WV, WK, WQ)                                                                          \
+  mma32(XA, WV, aV0); mma32(XB, WV, aV1); mma32(WK, XA, aK0); mma32(WK, XB, aK1); mma32(WQ, XA, aQ0); mma32(WQ, XB, aQ1);
+#define VITPE_A32_CHUNK(C, BUF, XO)                                                                                 \
+  {                                                                                                                 \
+    const bf16* const wb = wp + (BUF) * PBUF;                                                                       \
+    VITPE_A32_FENCE                                                                                                 \
+    const bf16x8 xa1 = ldsfrag(xp + (XO) + 16), xb1 = ldsfrag(xp + (XO) + 16 + 32 * LDX);                           \
+    const bf16x8 wv1 = ldsfrag(wb + 5 * 512), wk1 = ldsfrag(wb + 3 * 512), wq1 = ldsfrag(wb + 1 * 512);             \
+    VITPE_A32_FENCE                                                                                                 \
+    VITPE_A32_MMA6(xa, xb, wv, wk, wq)                                                                              \
+    VITPE_A32_FENCE                                                                                                 \
+    const bf16x8 xo = ldsfrag(xop + (XO));                                                                          \
+    const bf16x8 wo0 = ldsfrag(wbuf + (BUF) * PBUF + ooff[0]), wo1 = ldsfrag(wbuf + (BUF) * PBUF + ooff[1]),        \
+                 wo2 = ldsfrag(wbuf + (BUF) * PBUF + ooff[2]);                                                      \
+    pair_sync(C);                                                                                                   \
+    if ((C) + 2 < 6) dma_chunk((C) + 2, (BUF));                                                                     \
+    if (!(EXP & 1)) {                                                                                               \
+      od[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo0, xo, od[0], 0, 0, 0);                                     \
+      od[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo1, xo, od[1], 0, 0, 0);                                     \
+      od[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo2, xo, od[2], 0, 0, 0);                                     \
+    }                                                                                                               \
+    VITPE_A32_FENCE                                                                                                 \
+    xa = ldsfrag(xp + (XO) + 32); xb = ldsfrag(xp + (XO) + 32 + 32 * LDX);   /* (past the last chunk: in-bounds, unused) */ \
+    wv = ldsfrag(wp + (1 - (BUF)) * PBUF + 4 * 512); wk = ldsfrag(wp + (1 - (BUF)) * PBUF + 2 * 512);               \
+    wq = ldsfrag(wp + (1 - (BUF)) * PBUF + 0 * 512);                                                                \
+    VITPE_A32_FENCE                                                                                                 \
+    VITPE_A32_MMA6(xa1, xb1, wv1, wk1, wq1)                                                                         \
+    VITPE_A32_FENCE                                                                                                 \
   }
+  bf16x8 xa = ldsfrag(xp), xb = ldsfrag(xp + 32 * LDX);
+  bf16x8 wv = ldsfrag(wp + 4 * 512), wk = ldsfrag(wp + 2 * 512), wq = ldsfrag(wp + 0 * 512);
+  // matrix-pipe-bound phase at raised priority: once the oldest wave of a SIMD is in its (VALU-bound) softmax, the younger
+  // waves' MFMAs must still win the issue port -- the softmax fills the 24 free issue cycles of every 32-cycle MFMA
+  if (!(EXP & 8)) __builtin_amdgcn_s_setprio(2);
+#pragma unroll 1
+  for (int cp = 0; cp < 3; ++cp) {
+    VITPE_A32_CHUNK(2 * cp, 0, 0)
+    VITPE_A32_CHUNK(2 * cp + 1, 1, 32)
+    xp += 64;
+    xop += 64;
+  }
+#undef VITPE_A32_CHUNK
+#undef VITPE_A32_MMA6
+#undef VITPE_A32_FENCE
+  if (oc < 2) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) *reinterpret_cast<f32x4*>(&odd_raw[oc * 3 * D + 16 * ((h * 3 + t) * 2 + img) + 4 * og]) = od[t];
+  }
+  pair_sync(6);   // the odd token's rows are published to the partner
+  if (!(EXP & 8)) __builtin_amdgcn_s_setprio(0);
+  auto write_xn_out = [&]() {
+    // LayerNorm(x) for the backward pass, from the LDS image AFTER the k-loop: stored from the staging phase the 12.8 MB
+    // sat in front of every LDS-DMA piece in the in-order vmcnt queue, and the first handshakes waited for HBM writes
+    if (LNF && a.xn_out != nullptr) {
+      const int simg = tid / 384, st = tid % 384, cc = st % 24, r0 = st / 24;
+      if (blockIdx.x * 2 + simg < a.B) {
+        bf16* const obase = reinterpret_cast<bf16*>(a.xn_out) + (size_t)blockIdx.x * 2 * N * D;
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+          const int row = r0 + 16 * it;
+          if (it < 4 || row < N) {
+            const Chunk16 c16 = *reinterpret_cast<const Chunk16*>(xs_all + simg * W32::XIMG + row * LDX + cc * 8);
+            __builtin_nontemporal_store(c16, reinterpret_cast<Chunk16*>(obase + (unsigned)(simg * N + row) * (unsigned)D + (unsigned)(cc * 8)));
+          }
+        }
+      }
+    }
+  };
+  if (!MIXED) write_xn_out();
   stamp(3);
 
   // ---- v: acc[rho] = v[token 32 t + perm(rho, hh)][feature r] -> V^T operand fragments
   bf16x8 vf[4];
   vf[0] = pack8<0>(aV0); vf[1] = pack8<1>(aV0); vf[2] = pack8<0>(aV1); vf[3] = pack8<1>(aV1);
-  if (MIXED) {   // per-head tables -> the token region (free now), indexed by token like the axial table
+  if (MIXED) {   // per-head tables -> the token region (free once EVERY wave is through its k-loop), indexed by token
+    write_xn_out();
+    __syncthreads();
     for (int q = tid; q < H * N * 4; q += W32::NTH) {
       const int f4 = q & 3, row = (q >> 2) % N, t = (q >> 2) / N;
       f32x4 cv = {1.f, 1.f, 1.f, 1.f}, sv = {0.f, 0.f, 0.f, 0.f};
@@ -561,11 +648,17 @@ extern "C" int vitpe_fused_attention_fwd_wide(int dtype, const void* x, const fl
 // s_memtime at 0 start, 1 staged, 2 barrier passed, 3 k-loop done, 4 operand fragments built, 5 patch queries done, 6 end;
 // 8 = cycles inside the k-loop's barriers (incl. the LDS-DMA wait), 9 / 10 = s_memrealtime (100 MHz, chip-wide) at start / end
 extern "C" int vitpe_debug_attn32_census(const void* xn, const void* wqkv_wide, void* out, const float* cos,
-                                         const float* sin, int B, unsigned long long* census, hipStream_t stream) {
+                                         const float* sin, int B, unsigned long long* census, int exp, hipStream_t stream) {
   VITPE_REQUIRE(xn && wqkv_wide && out && cos && sin && census && B > 0);
   AttnArgs a{};
   a.xn = xn; a.wqkv = wqkv_wide; a.out = out; a.cos = cos; a.sin = sin; a.B = B; a.N = 65; a.mode = PE_ROPE_AXIAL; a.grid = 8;
   a.scale = 0.17677669f; a.census = census;
-  hipLaunchKernelGGL((attn32_fwd_kernel<KM_ROPE, false, false, true>), dim3((B + 1) / 2), dim3(768), 0, stream, a);
+  const dim3 grid((B + 1) / 2), block(768);
+  if (exp == 1) hipLaunchKernelGGL((attn32_fwd_kernel<KM_ROPE, false, false, true, 1>), grid, block, 0, stream, a);
+  else if (exp == 2) hipLaunchKernelGGL((attn32_fwd_kernel<KM_ROPE, false, false, true, 2>), grid, block, 0, stream, a);
+  else if (exp == 3) hipLaunchKernelGGL((attn32_fwd_kernel<KM_ROPE, false, false, true, 3>), grid, block, 0, stream, a);
+  else if (exp == 4) hipLaunchKernelGGL((attn32_fwd_kernel<KM_ROPE, false, false, true, 4>), grid, block, 0, stream, a);
+  else if (exp == 8) hipLaunchKernelGGL((attn32_fwd_kernel<KM_ROPE, false, false, true, 8>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((attn32_fwd_kernel<KM_ROPE, false, false, true>), grid, block, 0, stream, a);
   VITPE_CHECK_LAUNCH();
 }
