@@ -188,9 +188,9 @@ int vitpe_block_tail_fwd(int dtype, const void* attn_out, const void* x_in, cons
  *   Wp_packed = pack(attn.proj.weight [192,192], kchunk 192, phi 0)
  *   W1_packed = pack(mlp.fc1.weight  [HID,192], kchunk 192, phi 1)
  *   W2_packed = pack(mlp.fc2.weight  [192,HID], kchunk  32, phi 1)
- * What it keeps of the hidden layer for backward is h_out = gelu(u) and gp_out = gelu'(u) [M,HID] (NOT u: the
- * backward multiplies by the stored derivative, vitpe_block_tail_bwd with u_is_gprime = 1); pass both or, for
- * inference, neither.  bf16, D = 192, HID % 64 == 0, 128 <= HID <= 1536 (vitpe_block_tail2_supported); otherwise
+ * What it keeps of the hidden layer for backward is h_out = gelu(u) (bf16) and gp_out = gelu'(u) [M,HID] as IEEE HALF
+ * (2 bytes like bf16, 11 significant bits: vitpe_block_tail2_bwd multiplies every du element by it) -- NOT u: the
+ * backward multiplies by the stored derivative; pass both or, for inference, neither.  bf16, D = 192, HID % 64 == 0, 128 <= HID <= 1536 (vitpe_block_tail2_supported); otherwise
  * hipErrorNotSupported.
  * vitpe_pack_weight_frags: W fp32 [R,C] (R % 16 == 0, kchunk % 32 == 0, C % kchunk == 0) -> 1-KB fragments
  * (64 lanes x 8 elements) at fragment index ((kc * R/16 + nt) * kchunk/32 + ks); lane 16g + cc, element e holds
@@ -206,7 +206,7 @@ int vitpe_block_tail2_fwd(int dtype, const void* attn_out, const void* x_in, con
 /* vitpe_block_tail2_bwd: backward of vitpe_block_tail2_fwd w.r.t. its inputs, the same pipeline on the transposes:
  *   du = (dy fc2.weight) * gp  [M,HID] (stored: fc1's weight gradient reads it),  dx_mid = dy + LayerNorm2'(du fc1.weight)
  *   da = dx_mid attn.proj.weight  [M,192] (input of the attention backward);  dgamma / dbeta of norm2 accumulated (fp32
- *   atomics, one per column and workgroup).  gp = gelu'(u) as saved by vitpe_block_tail2_fwd; x_mid / mean2 / rstd2 its
+ *   atomics, one per column and workgroup).  gp = gelu'(u) as saved by vitpe_block_tail2_fwd (IEEE half); x_mid / mean2 / rstd2 its
  *   LayerNorm2 input rows and statistics.  Weights as vitpe_pack_weight_frags copies of the TRANSPOSES:
  *   W2t_packed = pack(fc2.weight^T [HID,192], kchunk 192, phi 1), W1t_packed = pack(fc1.weight^T [192,HID], kchunk 32, phi 1),
  *   WpT_packed = pack(attn.proj.weight^T [192,192], kchunk 192, phi 1).  Support as vitpe_block_tail2_fwd.                 */
@@ -239,7 +239,7 @@ int vitpe_block_tail_bwd(int dtype, const void* dy, const void* u, const void* W
                          const float* mean, const float* rstd, const float* gamma, void* du, void* dx,
                          float* dgamma, float* dbeta, const void* WpT, void* da, int M, int D, int HID,
                          vitpe_stream_t stream);
-/* vitpe_block_tail_bwd_gp: the same with gp = gelu'(u) [M,HID] (saved by vitpe_block_tail2_fwd) in place of u:
+/* vitpe_block_tail_bwd_gp: the same with gp = gelu'(u) [M,HID] in T in place of u (first-generation kernel):
  *   du = (dy fc2.weight) * gp -- no erf evaluation in the backward.                                              */
 int vitpe_block_tail_bwd_gp(int dtype, const void* dy, const void* gp, const void* W2t, const void* W1t, const void* x,
                          const float* mean, const float* rstd, const float* gamma, void* du, void* dx,
@@ -390,7 +390,7 @@ int vitpe_transpose_cast(int dtype, const float* src, void* dst, int R, int C, v
  *  kind, HD, kind2, HD2, pad}: the fp32 matrix [R,C] at src_off is written as shadow `kind` at dst_off and, when
  *  kind2 >= 0, as shadow `kind2` at dst_off2 (one load of the source tile for both).  kind: 0 = transpose,
  *  1 = vitpe_pack_qkv_weights layout (HD = head dim), 2 / 3 = vitpe_pack_weight_frags of the matrix (natural / phi k
- *  order, HD = k chunk), 4 / 5 = vitpe_pack_weight_frags of its TRANSPOSE.  tile0 = running sum of
+ *  order, HD = k chunk), 4 / 5 = vitpe_pack_weight_frags of its TRANSPOSE, 6 = vitpe_pack_qkv_weights_wide (HD = 32).  tile0 = running sum of
  *  ceil(R/32)*ceil(C/32); total_tiles = that sum over all records; tile_map (nullable): uint16[total_tiles], the record
  *  index of every 32x32 tile (without it each workgroup scans the records).                                        */
 int vitpe_refresh_shadows(int dtype, const float* flat, void* dst_base, const void* desc, int ndesc,

@@ -101,12 +101,7 @@ def compare_all(tagname, model, grads, ref_grads, report):
             worst["rel"], worst["rel_at"] = r, n
         if c < worst["cos"]:
             worst["cos"], worst["cos_at"] = c, n
-        # The SHARED polynomial coefficients (one [degree+1] vector for all heads and layers) are a sum of per-head
-        # contributions that largely cancel: their max-norm error moves between 0.02 and 0.09 with the rounding points of
-        # the bf16 pipeline (first-generation block tail 0.020, second generation -- gelu'(u) saved in bf16 -- 0.088; the
-        # per-head variant of the same tensor stays at 0.0015 and the fp32 engine at 2e-5), so that one tensor gets a wider
-        # max-norm gate; its direction (cosine >= 0.999) is held like everyone else's.
-        if r > (0.15 if (tagname == "polynomial" and n == "pos_embed.coefficients") else 5e-2):
+        if r > 5e-2:
             bad.append((n, "rel", r))
         if c < 0.999:
             bad.append((n, "cos", c))
@@ -126,6 +121,30 @@ def _dump(report, name):
         f.write(json.dumps(report) + "\n")
 
 
+def _captured_step_against_oracle(tag, extra, B, report_name):
+    from vitpe.engine import TrainEngine
+    cfg, model = build(tag, extra, {}, seeded=True)
+    params = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+    if tag == "rope-axial":
+        params["pos_embed.inv_freq"] = model.pos_embed.inv_freq.cpu()
+    g = torch.Generator().manual_seed(11)
+    images, labels = torch.randn(B, 3, 32, 32, generator=g), torch.randint(0, 10, (B,), generator=g)
+    ref_logits, ref_loss, ref_grads = O.loss_and_grads(cfg, params, images, labels)
+    eng = TrainEngine(model, B, compute_dtype=torch.bfloat16, use_graph=True)
+    assert eng.attn_fused and eng.fuse_ln and eng.fuse_ln_bwd and eng.fuse_mlp and eng.fuse_tail and eng.group_wgrad
+    assert eng.attn_wide == (os.environ.get("VITPE_ATTN_WIDE", "1") == "1")     # the 32x32-tile forward is what the step runs
+    grads = graph_step_gradients(eng, images.cuda(), labels.cuda())
+    assert eng.graph_fb is not None
+    report = {}
+    key = tag if B == 16 else f"{tag}@B{B}"
+    bad = compare_all(key, model, grads, ref_grads, report)
+    report[key]["logits"] = rel_err(eng.logits.cpu(), ref_logits)
+    _dump(report, report_name)
+    assert rel_err(eng.logits.cpu(), ref_logits) <= 5e-2
+    assert abs(float(eng.out2[0]) - float(ref_loss)) <= 2e-2
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("tag,extra", MODES)
 def test_bf16_captured_step_gradients_full_cifar_geometry(tag, extra):
     """d=192, L=6, H=6 (BASELINE configs 2-4), B=16, bf16, default fusions, HIP graph: what bench.py times, on the
@@ -137,26 +156,16 @@ def test_bf16_captured_step_gradients_full_cifar_geometry(tag, extra):
     activation format reproduces the early layers' gradients to 10-30 % only -- identical figures with every fusion
     switched off, 2e-5 in fp32: tools/diag_closed_form.py.  The fp32 engine is checked on those weights at the full
     geometry in test_fp32_engine_full_cifar_geometry_closed_form_weights below.)"""
-    from vitpe.engine import TrainEngine
-    cfg, model = build(tag, extra, {}, seeded=True)
-    params = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
-    if tag == "rope-axial":
-        params["pos_embed.inv_freq"] = model.pos_embed.inv_freq.cpu()
-    B = 16
-    g = torch.Generator().manual_seed(11)
-    images, labels = torch.randn(B, 3, 32, 32, generator=g), torch.randint(0, 10, (B,), generator=g)
-    ref_logits, ref_loss, ref_grads = O.loss_and_grads(cfg, params, images, labels)
-    eng = TrainEngine(model, B, compute_dtype=torch.bfloat16, use_graph=True)
-    assert eng.attn_fused and eng.fuse_ln and eng.fuse_ln_bwd and eng.fuse_mlp and eng.fuse_tail and eng.group_wgrad
-    grads = graph_step_gradients(eng, images.cuda(), labels.cuda())
-    assert eng.graph_fb is not None
-    report = {}
-    bad = compare_all(tag, model, grads, ref_grads, report)
-    report[tag]["logits"] = rel_err(eng.logits.cpu(), ref_logits)
-    _dump(report, "bench_path_parity.jsonl")
-    assert rel_err(eng.logits.cpu(), ref_logits) <= 5e-2
-    assert abs(float(eng.out2[0]) - float(ref_loss)) <= 2e-2
-    assert not bad, bad
+    _captured_step_against_oracle(tag, extra, 16, "bench_path_parity.jsonl")
+
+
+@pytest.mark.parametrize("tag", ["rope-axial", "polynomial"])
+def test_bf16_captured_step_gradients_at_the_benchmark_batch(tag):
+    """The same at B = 512, the batch the metric is quoted on: 2080 token tiles over 256 CUs (the nine-tile block-tail
+    workgroups and their split ninth tile), two full rounds of the weight-gradient windows at M = 33 280, a chip-full
+    of two-image attention workgroups -- every gradient of the captured step against the oracle (rope-axial = BASELINE
+    config 2, polynomial = the mode whose coefficient gradient is the most rounding-sensitive tensor of the model)."""
+    _captured_step_against_oracle(tag, {}, 512, "bench_path_parity.jsonl")
 
 
 def test_fp32_engine_full_cifar_geometry_closed_form_weights():

@@ -149,6 +149,36 @@ def test_attention_module_vs_reference_golden(golden):
             assert rel_err(p.grad.cpu(), g[f"{tag}/dpe.{n}"]) < 2e-4, (tag, n)
 
 
+def test_attention_uses_the_callers_rotary_tables():
+    """Attention.forward(x, freqs_cis=(cos, sin)) rotates with the tensors it is handed (reference vit.py:51-64), not
+    with tables regenerated from the module: perturbed tables against the oracle's attention core, fp32 and (on the
+    32x32-tile kernel's geometry) bf16; a mis-shaped table raises reshape_for_broadcast's ValueError."""
+    from models.vit import Attention
+    from models import positional_encoding as pe
+    for D, H, dt, tol in ((96, 3, torch.float32, 1e-4), (192, 6, torch.bfloat16, 3e-2)):
+        N, hd, B = 65, D // H, 3
+        att = Attention(D, num_heads=H)
+        att.set_pos_encoding(pe.RoPEAxial(hd, 100.0))
+        with torch.no_grad():
+            att.qkv.weight.copy_(O.closed_form_tensor("attn.qkv.weight", (3 * D, D)) * 4)
+            att.proj.weight.copy_(O.closed_form_tensor("attn.proj.weight", (D, D)) * 4)
+            att.proj.bias.copy_(O.closed_form_tensor("attn.proj.bias", (D,)))
+        att.cuda()
+        x = (O.closed_form_tensor("attn.x", (B, N, D)) * 20)
+        ang = torch.linspace(0.0, 2.5, (N - 1) * (hd // 2)).reshape(N - 1, hd // 2) ** 1.3        # not the module's angles
+        for tabs in (ang, torch.stack([ang * (1 + 0.1 * h) for h in range(H)])):                   # [P, hd/2] and [H, P, hd/2]
+            cos, sin = torch.cos(tabs), torch.sin(tabs)
+            y = att(x.cuda().to(dt), freqs_cis=(cos.cuda(), sin.cuda()))
+            xq = x.to(dt).float()
+            wq = att.qkv.weight.detach().cpu().to(dt).float()
+            qkv = (xq @ wq.t()).reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+            o = O.attention_core(qkv[0], qkv[1], qkv[2], hd ** -0.5, (cos, sin), None).transpose(1, 2).reshape(B, N, D)
+            ref = o.to(dt).float() @ att.proj.weight.detach().cpu().to(dt).float().t() + att.proj.bias.detach().cpu()
+            assert rel_err(y.float().cpu(), ref) < tol, (D, tabs.dim())
+        with pytest.raises(ValueError, match="Unexpected shape for freqs_cis"):
+            att(x.cuda().to(dt), freqs_cis=(cos.cuda()[:, :-1], sin.cuda()[:, :-1]))
+
+
 def test_pe_module_api_surface(golden):
     """get_bias / get_freqs_cis / apply_rotary_emb on the drop-in classes (visualizer surface)."""
     from models import positional_encoding as pe

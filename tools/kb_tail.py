@@ -64,7 +64,7 @@ def main():
         K.block_tail_bwd(dy[i], u[i], w2tb, w1tb, xm[i], m2, r2, gam, dg, db, wptb, du=du[i], out=dxm[i], da=da[i], u_is_gprime=True)
 
     def bwd2(i):
-        K.block_tail2_bwd(dy[i], u[i], w2tk, w1tk, xm[i], m2, r2, gam, dg, db, wptk, du=du[i], out=dxm[i], da=da[i])
+        K.block_tail2_bwd(dy[i], u[i].view(torch.float16), w2tk, w1tk, xm[i], m2, r2, gam, dg, db, wptk, du=du[i], out=dxm[i], da=da[i])
 
     for name, fn in (("block_tail_fwd  (gen 1)", gen1), ("block_tail2_fwd (gen 2)", gen2),
                      ("block_tail2_fwd no xn", lambda i: gen2(i, store_xn=False)),

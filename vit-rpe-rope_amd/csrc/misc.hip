@@ -679,7 +679,8 @@ __global__ void transpose_cast_kernel(const float* __restrict__ src, T* __restri
 // All weight shadows of the model in ONE launch (after the optimizer step): a descriptor per matrix,
 // each workgroup handles one 32x32 tile.  kind 0: dst[c][r] = src[r][c] (transposed shadow for the
 // data-gradient GEMMs); kind 1: fragment-major packing of attn.qkv.weight (see pack_qkv_kernel); kind 2 / 3: the
-// fragment-major packing of tail2.hip (natural / acc_to_frag k order, HD field = k chunk); kind 4 / 5: the same of W^T.
+// fragment-major packing of tail2.hip (natural / acc_to_frag k order, HD field = k chunk); kind 4 / 5: the same of W^T;
+// kind 6: the wide qkv pack of attn32.hip (HD field = head dim = 32).
 // A descriptor may name a SECOND shadow of the same matrix (kind2 >= 0): the source tile is loaded once for both (a weight
 // and its transpose packs, the qkv pack and its transposed pack).  tile_map[block] = descriptor index (host-built; without
 // it every block scans the descriptor list -- 48 dependent-latency loads per block were most of this kernel's time).
@@ -713,6 +714,20 @@ __global__ __launch_bounds__(256) void refresh_shadows_kernel(const float* __res
       for (int i = ty; i < 32; i += 8) {
         const int c = c0 + i, r = r0 + tx;
         if (c < ds.C && r < ds.R) dst[(size_t)c * ds.R + r] = from_f32<T>(tile[tx][i]);
+      }
+    } else if (kind == 6) {
+      // wide pack of attn.qkv.weight (csrc/attn32.hip, vitpe_pack_qkv_weights_wide): block ((h * 3 + mat) * (D / 16) + s),
+      // lane (r = row % 32) + 32 * hh, element j <- W[mat D + 32 h + r][16 s + 8 hh + j]; q rows x hd^-0.5 log2(e)
+      const int D = ds.C, S = D / 16;
+      const float qs = 1.4426950408889634f * rsqrtf((float)hd);
+      for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        if (r < ds.R && c < ds.C) {
+          const int mat = r / D, rr = r % D, h = rr / 32, f = rr % 32;
+          const int sidx = c / 16, hh = (c % 16) / 8, e = c % 8;
+          const size_t blk = ((size_t)(h * 3 + mat) * S + sidx);
+          dst[(blk * 64 + f + 32 * hh) * 8 + e] = from_f32<T>(tile[i][tx] * (mat == 0 ? qs : 1.0f));
+        }
       }
     } else if (kind >= 2) {
       // vitpe_pack_weight_frags layout (tail2.hip): hd = k chunk; kinds 2 / 3 pack W itself in natural / acc_to_frag

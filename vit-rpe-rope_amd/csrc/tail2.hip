@@ -60,7 +60,7 @@ struct Tail2Args {
   float* mean2;         // [M] LayerNorm2 statistics of x_mid, out
   float* rstd2;
   void* xn_out;         // [M,192] LayerNorm2(x_mid), nullable
-  void* gp_out;         // [M,HID] gelu'(u)   (SAVE only)
+  void* gp_out;         // [M,HID] gelu'(u) as IEEE half (SAVE only)
   void* h_out;          // [M,HID] gelu(u)    (SAVE only)
   void* out;            // [M,192]
   float* mean_out;      // statistics of the output rows (next norm1), nullable (both or neither)
@@ -99,6 +99,28 @@ VITPE_DEV void t2_store_pair(bf16* rowp, int nt0, int g, const f32x4& o0, const 
     pa[0] = (bf16)o0[2 * w2]; pa[1] = (bf16)o0[2 * w2 + 1];
     pb[0] = (bf16)o1[2 * w2]; pb[1] = (bf16)o1[2 * w2 + 1];
     const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, pa), __builtin_bit_cast(uint32_t, pb), false, false);
+    lo[w2] = r[0]; hi[w2] = r[1];
+  }
+  const int f0 = 16 * (nt0 + (g & 1)) + 8 * (g >> 1);
+  const Chunk16 v = {lo[0], lo[1], hi[0], hi[1]};
+  if (NONTEMPORAL) __builtin_nontemporal_store(v, reinterpret_cast<Chunk16*>(rowp + f0));
+  else *reinterpret_cast<Chunk16*>(rowp + f0) = v;
+}
+
+// The same for gelu'(u), kept as IEEE half (round toward zero, v_cvt_pkrtz_f16_f32: one instruction per pair like the bf16
+// conversion).  |gelu'| <= 1.13 needs no exponent range, and the backward multiplies EVERY du element by this value: rounded
+// to bf16 (8 significant bits) it put 2^-9 of relative noise on all of them, which the cancelling sums of the backward
+// (the shared polynomial-RPE coefficients: a sum over heads, layers and token pairs that mostly cancels) amplified to
+// 9 % of their max norm; 11 bits bring that back to what recomputing gelu'(u) from the bf16 u gives (round-3 log).
+typedef __attribute__((ext_vector_type(2))) _Float16 t2_half2;
+template <bool NONTEMPORAL>
+VITPE_DEV void t2_store_pair_f16(bf16* rowp, int nt0, int g, const f32x4& o0, const f32x4& o1) {
+  uint32_t lo[2], hi[2];
+#pragma unroll
+  for (int w2 = 0; w2 < 2; ++w2) {
+    const uint32_t pa = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(o0[2 * w2], o0[2 * w2 + 1]));
+    const uint32_t pb = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(o1[2 * w2], o1[2 * w2 + 1]));
+    const auto r = __builtin_amdgcn_permlane16_swap(pa, pb, false, false);
     lo[w2] = r[0]; hi[w2] = r[1];
   }
   const int f0 = 16 * (nt0 + (g & 1)) + 8 * (g >> 1);
@@ -237,7 +259,7 @@ VITPE_DEV void t2_substep(const bf16* w1f, const bf16* w2f, const Frag<bf16> (&b
       }
     }
     if (SAVE && !(EXP & 4)) {
-      t2_store_pair<T2_NT_HID>(gpr, 0, g, gp[0], gp[1]);      // read again only in backward
+      t2_store_pair_f16<T2_NT_HID>(gpr, 0, g, gp[0], gp[1]);  // read again only in backward; IEEE half (see t2_store_pair_f16)
       t2_store_pair<T2_NT_HID>(hr, 0, g, hh[0], hh[1]);
     }
     hnew = acc_to_frag<bf16>(hh[0], hh[1]);
@@ -566,7 +588,7 @@ __global__ __launch_bounds__(T2F_THREADS) void block_tail2_fwd_kernel(Tail2Args 
 //   da  = dx_mid Wp        A = attn.proj.weight^T (acc_to_frag order), loaded into the slab buffers once they are free
 struct Tail2BwdArgs {
   const void* dy;       // [M,192] gradient of the block output
-  const void* gp;       // [M,HID] gelu'(u) (vitpe_block_tail2_fwd)
+  const void* gp;       // [M,HID] gelu'(u) as IEEE half (vitpe_block_tail2_fwd)
   const void* xmid;     // [M,192] LayerNorm2's input rows
   const float* mean2;   // [M]
   const float* rstd2;
@@ -604,6 +626,17 @@ VITPE_DEV void t2_unpack_pair(const Chunk16& v, f32x4& o0, f32x4& o1) {
     o0[2 * w2 + 1] = __uint_as_float(r[0] & 0xffff0000u);
     o1[2 * w2] = __uint_as_float(r[1] << 16);
     o1[2 * w2 + 1] = __uint_as_float(r[1] & 0xffff0000u);
+  }
+}
+
+// ... of a row piece stored by t2_store_pair_f16 (gelu'(u), IEEE half)
+VITPE_DEV void t2_unpack_pair_f16(const Chunk16& v, f32x4& o0, f32x4& o1) {
+#pragma unroll
+  for (int w2 = 0; w2 < 2; ++w2) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v[w2], v[2 + w2], false, false);
+    const t2_half2 a = __builtin_bit_cast(t2_half2, r[0]), b = __builtin_bit_cast(t2_half2, r[1]);
+    o0[2 * w2] = (float)a[0]; o0[2 * w2 + 1] = (float)a[1];
+    o1[2 * w2] = (float)b[0]; o1[2 * w2 + 1] = (float)b[1];
   }
 }
 
@@ -864,7 +897,7 @@ __global__ __launch_bounds__(T2_THREADS) void block_tail2_bwd_kernel(Tail2BwdArg
   // G stage of sub-chunk t: du = dh * gelu'(u) -> stored, -> B fragment of the F2 product; refills its prefetch slot
   auto gstage = [&](const f32x4 (&a1c)[2], Chunk16& slot, int t, Frag<T>& hnew) {
     f32x4 g0, g1, d0, d1;
-    t2_unpack_pair(slot, g0, g1);
+    t2_unpack_pair_f16(slot, g0, g1);
     if (t + 2 < nsub) slot = *reinterpret_cast<const Chunk16*>(gpr + 32 * (t + 2));
 #pragma unroll
     for (int r = 0; r < 4; ++r) { d0[r] = a1c[0][r] * g0[r]; d1[r] = a1c[1][r] * g1[r]; }

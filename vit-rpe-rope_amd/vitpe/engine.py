@@ -75,13 +75,16 @@ class TrainEngine:
         self.attn_fused = K.fused_attention_supported(self.T, self.N, self.D, self.D // self.H)
         if not self.attn_fused and not K.attention_core_supported(self.T, self.N, self.D // self.H):
             raise L.VitpeError(f"no attention kernel for N={self.N}, D={self.D}, hd={self.D // self.H}")
+        # the 32x32-tile forward kernel (csrc/attn32.hip) for the benchmark geometry; VITPE_ATTN_WIDE=0: the 16x16-tile one
+        self.attn_wide = (self.attn_fused and K.fused_attention_wide_supported(self.T, self.N, self.D, self.D // self.H)
+                          and os.environ.get("VITPE_ATTN_WIDE", "1") == "1")
         if not self.attn_fused:   # the LayerNorm / MLP fusions hang off the fused attention kernels' geometry
             self.fuse_ln = self.fuse_ln_bwd = self.fuse_mlp = False
         # second-generation block-tail forward (a wave per 16-token tile, hidden activation in registers, weights as
         # fragment-packed shadows, gelu'(u) saved instead of u); VITPE_TAIL2=0 keeps the first generation
         self.tail2 = (self.fuse_mlp and self.fuse_ln_bwd and self.fuse_tail and os.environ.get("VITPE_TAIL2", "1") == "1"
                       and K.block_tail2_supported(self.T, self.D, self.hid))
-        self.tail2_bwd = os.environ.get("VITPE_TAIL2_BWD", "1") == "1"   # (0: first-generation backward on the saved gelu')
+        self.tail2_bwd = True   # (block_tail2_fwd keeps gelu'(u) as IEEE half: only the second-generation backward reads it)
         # qkv data gradient + LayerNorm1 backward on the same mapping (29.5 vs 31.4 us for the panel kernel; VITPE_LNBWD2=0:
         # the panel kernel on the transposed shadow)
         self.lnbwd2 = self.tail2 and self.tail2_bwd and os.environ.get("VITPE_LNBWD2", "1") == "1"
@@ -124,6 +127,7 @@ class TrainEngine:
         # weights (attention kernels): one flat buffer, refreshed by ONE batched kernel per step
         self._st: Dict[int, torch.Tensor] = {}
         self._pk: Dict[int, torch.Tensor] = {}
+        self._pkw: Dict[int, torch.Tensor] = {}
         self._fr: Dict[int, torch.Tensor] = {}
         self._frt: Dict[int, torch.Tensor] = {}
         self._gemm_weights: List[nn.Parameter] = []
@@ -154,6 +158,8 @@ class TrainEngine:
             # (block_tail2_fwd), 4 / 5 fragment packs of the transposes (block_tail2_bwd, linear_lnbwd2)
             if self.attn_fused:
                 add(qkv, 1, HDh, *((4, 64) if self.lnbwd2 else (0, 0)))
+                if self.attn_wide:
+                    add(qkv, 6, HDh)
             else:
                 add(qkv, 0, 0)
             if self.tail2:
@@ -170,6 +176,8 @@ class TrainEngine:
                 self._st[id(w)] = self._shadow_flat[o:o + R * C].view(C, R)
             elif kind == 1:
                 self._pk[id(w)] = self._shadow_flat[o:o + R * C].view(R, C)
+            elif kind == 6:
+                self._pkw[id(w)] = self._shadow_flat[o:o + R * C]
             elif kind < 4:
                 self._fr[id(w)] = self._shadow_flat[o:o + R * C].view(R, C)
             else:
@@ -206,6 +214,15 @@ class TrainEngine:
 
     def Pk(self, prm):  # packed qkv weights
         return self._pk[id(prm)]
+
+    def Pkw(self, prm):  # wide pack of the qkv weights (32x32-tile attention forward)
+        return self._pkw[id(prm)]
+
+    def _attn_fwd(self, x, blk, out, ln=None, xn_out=None):
+        """The fused attention forward the step runs: the wide kernel where its geometry applies."""
+        if self.attn_wide:
+            return K.fused_attention_fwd_wide(x, self.Pkw(blk.attn.qkv.weight), self.H, self.pe, out=out, ln=ln, xn_out=xn_out)
+        return K.fused_attention_fwd(x, self.Pk(blk.attn.qkv.weight), self.H, self.pe, out=out, ln=ln, xn_out=xn_out)
 
     def Fr(self, prm):  # fragment-major packed copy (block_tail2_fwd)
         return self._fr[id(prm)]
@@ -324,8 +341,8 @@ class TrainEngine:
             if self.fuse_ln:
                 # LN1 inside the attention kernel's token staging; LN2 inside fc1's operand staging; their
                 # statistics come out of the producing GEMM's epilogue (proj / previous fc2)
-                K.fused_attention_fwd(xin, self.Pk(blk.attn.qkv.weight), self.H, self.pe, out=a["a"],
-                                      ln=(blk.norm1.weight.data, blk.norm1.bias.data, a["m1"], a["r1"]), xn_out=a["xn1"])   # (xn1 is None when recompute_ln)
+                self._attn_fwd(xin, blk, a["a"], ln=(blk.norm1.weight.data, blk.norm1.bias.data, a["m1"], a["r1"]),
+                               xn_out=a["xn1"])   # (xn1 is None when recompute_ln)
                 nxt = (self.act[l + 1]["m1"], self.act[l + 1]["r1"]) if l + 1 < self.Lyr else None
                 eps_next = mdl.blocks[min(l + 1, self.Lyr - 1)].norm1.eps
                 if self.fuse_mlp and self.fuse_tail:   # proj + residual + LN2 + MLP branch: one kernel per block tail
@@ -349,7 +366,7 @@ class TrainEngine:
             K.layernorm_fwd(xin, blk.norm1.weight.data, blk.norm1.bias.data, blk.norm1.eps, out=a["xn1"],
                             mean=a["m1"], rstd=a["r1"])
             if self.attn_fused:
-                K.fused_attention_fwd(a["xn1"], self.Pk(blk.attn.qkv.weight), self.H, self.pe, out=a["a"])
+                self._attn_fwd(a["xn1"], blk, a["a"])
             else:
                 K.linear(a["xn1"].view(M, D), self.Sh(blk.attn.qkv.weight), None, out=self.qkv_l[l].view(M, 3 * D))
                 K.attention_core_fwd(self.qkv_l[l], self.H, self.pe, out=a["a"])
@@ -375,7 +392,7 @@ class TrainEngine:
                               self.Fr(blk.mlp.fc1.weight), blk.mlp.fc1.bias.data, self.Fr(blk.mlp.fc2.weight),
                               blk.mlp.fc2.bias.data, x_mid=a["xmid"].view(M, D), mean2=a["m2"], rstd2=a["r2"],
                               xn_out=(a["xn2"].view(M, D) if (save and not self.recompute_ln) else None),
-                              gp=(a["u"] if save else None), h=(a["h"] if save else None), out=self.x[l + 1].view(M, D),
+                              gp=(a["u"].view(torch.float16) if save else None), h=(a["h"] if save else None), out=self.x[l + 1].view(M, D),
                               stats=nxt, eps2=blk.norm2.eps, eps_next=eps_next, save=save)
             return
         K.block_tail_fwd(a["a"].view(M, D), self.x[l].view(M, D), self.Sh(blk.attn.proj.weight),
@@ -393,13 +410,13 @@ class TrainEngine:
             up, ua = self.model.blocks[l + 1], self.act[l + 1]
             K.block_tail2_bwd_pre(self.dqkv_l[l + 1].view(M, 3 * D), self.Frt(up.attn.qkv.weight), self.x[l + 1].view(M, D),
                                   ua["m1"], ua["r1"], up.norm1.weight.data, self.dx_mid[l + 1].view(M, D), G(up.norm1.weight),
-                                  G(up.norm1.bias), self.dx_out[l + 1].view(M, D), a["u"], self.Frt(blk.mlp.fc2.weight),
+                                  G(up.norm1.bias), self.dx_out[l + 1].view(M, D), a["u"].view(torch.float16), self.Frt(blk.mlp.fc2.weight),
                                   self.Frt(blk.mlp.fc1.weight), a["xmid"].view(M, D), a["m2"], a["r2"], blk.norm2.weight.data,
                                   G(blk.norm2.weight), G(blk.norm2.bias), self.Frt(blk.attn.proj.weight), du=self.du_l[l],
                                   out=self.dx_mid[l].view(M, D), da=self.dtmp.view(M, D))
             return
         if self.tail2 and self.tail2_bwd:
-            K.block_tail2_bwd(self.dx_out[l + 1].view(M, D), a["u"], self.Frt(blk.mlp.fc2.weight), self.Frt(blk.mlp.fc1.weight),
+            K.block_tail2_bwd(self.dx_out[l + 1].view(M, D), a["u"].view(torch.float16), self.Frt(blk.mlp.fc2.weight), self.Frt(blk.mlp.fc1.weight),
                               a["xmid"].view(M, D), a["m2"], a["r2"], blk.norm2.weight.data, G(blk.norm2.weight),
                               G(blk.norm2.bias), self.Frt(blk.attn.proj.weight), du=self.du_l[l],
                               out=self.dx_mid[l].view(M, D), da=self.dtmp.view(M, D))
@@ -772,10 +789,9 @@ class TrainEngine:
             def fwd(l):
                 blk, a = mdl.blocks[l], self.act[l]
                 if self.fuse_ln:
-                    return lambda: K.fused_attention_fwd(self.x[l], self.Pk(blk.attn.qkv.weight), Hh, self.pe, out=a["a"],
-                                                         ln=(blk.norm1.weight.data, blk.norm1.bias.data, a["m1"], a["r1"]),
-                                                         xn_out=a["xn1"])
-                return lambda: K.fused_attention_fwd(a["xn1"], self.Pk(blk.attn.qkv.weight), Hh, self.pe, out=a["a"])
+                    return lambda: self._attn_fwd(self.x[l], blk, a["a"], ln=(blk.norm1.weight.data, blk.norm1.bias.data,
+                                                                              a["m1"], a["r1"]), xn_out=a["xn1"])
+                return lambda: self._attn_fwd(a["xn1"], blk, a["a"])
             def bwd(l):
                 blk, a = mdl.blocks[l], self.act[l]
                 if self.recompute_ln:
@@ -784,11 +800,12 @@ class TrainEngine:
                                                                                  a["m1"], a["r1"]), **self.pe_grads)
                 return lambda: K.fused_attention_bwd(a["xn1"], self.Pk(blk.attn.qkv.weight), self.dx_mid[l], Hh, self.pe,
                                                      out=self.dqkv_l[l], **self.pe_grads)
-            probes.append(dict(name="attn_fwd", kernel="attn_fwd_kernel (fused LN1+QKV-project+RoPE+QK^T+softmax+AV)",
+            probes.append(dict(name="attn_fwd", kernel=("attn32_fwd_kernel" if self.attn_wide else "attn_fwd_kernel") +
+                               " (fused LN1+QKV-project+RoPE+QK^T+softmax+AV)",
                                fns=[fwd(l) for l in range(self.Lyr)], flop=qkv_flop + attn_core_flop,
                                bytes=2 * M * D * es))           # x in, merged heads out (49 920 B / image)
             if not self.fuse_ln:
-                probes[-1]["kernel"] = "attn_fwd_kernel (fused QKV-project+RoPE+QK^T+softmax+AV)"
+                probes[-1]["kernel"] = probes[-1]["kernel"].replace("fused LN1+", "fused ")
             probes.append(dict(name="attn_bwd", kernel="attn_bwd_kernel (recompute + dQ/dK/dV + PE gradients -> d_qkv)",
                                fns=[bwd(l) for l in range(self.Lyr)], flop=2 * (qkv_flop + attn_core_flop),
                                bytes=(2 + 3) * M * D * es))     # xn, dout in; d_qkv out

@@ -210,9 +210,9 @@ def block_tail2_fwd(attn_out, x_in, wp_pk, bp, gamma, beta, w1_pk, b1, w2_pk, b2
     mean2 = mean2 if mean2 is not None else torch.empty(M, dtype=torch.float32, device=dev)
     rstd2 = rstd2 if rstd2 is not None else torch.empty(M, dtype=torch.float32, device=dev)
     if save:
-        gp = gp if gp is not None else torch.empty((M, HID), dtype=dt, device=dev)
+        gp = gp if gp is not None else torch.empty((M, HID), dtype=torch.float16, device=dev)   # gelu'(u) is kept as IEEE half
         h = h if h is not None else torch.empty((M, HID), dtype=dt, device=dev)
-        assert gp.shape == h.shape == (M, HID) and gp.dtype == h.dtype == dt
+        assert gp.shape == h.shape == (M, HID) and h.dtype == dt and gp.dtype == torch.float16
     else:
         gp = h = None
     out = out if out is not None else torch.empty((M, D), dtype=dt, device=dev)
@@ -266,9 +266,10 @@ def block_tail2_bwd(dy, gp, w2t_pk, w1t_pk, x_mid, mean2, rstd2, gamma, dgamma, 
     M, D = dy.shape
     HID = gp.shape[1]
     assert gp.shape == (M, HID) and x_mid.shape == (M, D) and w2t_pk.numel() == HID * D and w1t_pk.numel() == HID * D
-    assert wpt_pk.numel() == D * D and dy.dtype == gp.dtype == w2t_pk.dtype == w1t_pk.dtype == x_mid.dtype == wpt_pk.dtype
+    assert wpt_pk.numel() == D * D and dy.dtype == w2t_pk.dtype == w1t_pk.dtype == x_mid.dtype == wpt_pk.dtype
+    assert gp.dtype == torch.float16   # (block_tail2_fwd keeps gelu'(u) as IEEE half)
     _f32(gamma, "gamma"), _f32(dgamma, "dgamma"), _f32(dbeta, "dbeta"), _f32(mean2, "mean2"), _f32(rstd2, "rstd2")
-    du = du if du is not None else torch.empty_like(gp)
+    du = du if du is not None else torch.empty(gp.shape, dtype=dy_out.dtype, device=dy_out.device)
     out = out if out is not None else torch.empty_like(dy)
     da = da if da is not None else torch.empty_like(dy)
     check(lib().vitpe_block_tail2_bwd(dtype_code(dy.dtype), ptr(dy), ptr(gp), ptr(w2t_pk), ptr(w1t_pk), ptr(x_mid), ptr(mean2),
@@ -286,11 +287,12 @@ def block_tail2_bwd_pre(dqkv, wqt_pk, x1, mean1, rstd1, gamma1, dres1, dgamma1, 
     M, K1 = dqkv.shape
     D, HID = dy_out.shape[1], gp.shape[1]
     assert dy_out.shape == (M, D) and gp.shape == (M, HID) and x_mid.shape == (M, D) and wqt_pk.numel() == D * K1
-    assert dqkv.dtype == wqt_pk.dtype == dy_out.dtype == gp.dtype == w2t_pk.dtype == w1t_pk.dtype == x_mid.dtype == wpt_pk.dtype
+    assert dqkv.dtype == wqt_pk.dtype == dy_out.dtype == w2t_pk.dtype == w1t_pk.dtype == x_mid.dtype == wpt_pk.dtype
+    assert gp.dtype == torch.float16
     for t_, n_ in ((gamma, "gamma"), (dgamma, "dgamma"), (dbeta, "dbeta"), (gamma1, "gamma1"), (dgamma1, "dgamma1"),
                    (dbeta1, "dbeta1"), (mean1, "mean1"), (rstd1, "rstd1"), (mean2, "mean2"), (rstd2, "rstd2")):
         _f32(t_, n_)
-    du = du if du is not None else torch.empty_like(gp)
+    du = du if du is not None else torch.empty(gp.shape, dtype=dy_out.dtype, device=dy_out.device)
     out = out if out is not None else torch.empty_like(dy_out)
     da = da if da is not None else torch.empty_like(dy_out)
     check(lib().vitpe_block_tail2_bwd_pre(dtype_code(dqkv.dtype), ptr(dqkv), ptr(wqt_pk), ptr(x1), ptr(mean1), ptr(rstd1),

@@ -29,9 +29,12 @@ def _shadow_t(w: Tensor, dtype) -> Tensor:
 
 
 def _pe_tables(mode: int, grid: int, pe_param: Optional[Tensor], inv_freq: Optional[Tensor], degree: int,
-               per_head: bool) -> K.PETables:
+               per_head: bool, cos: Optional[Tensor] = None, sin: Optional[Tensor] = None) -> K.PETables:
     name = MODES[mode]
     t = K.PETables(name, grid, degree=degree, coeff_per_head=per_head)
+    if cos is not None:   # the caller's own (cos, sin) tables (reference vit.py:51-64 rotates with what it is handed)
+        t.cos, t.sin = cos.float().contiguous(), sin.float().contiguous()
+        return t
     if name == "relative":
         t.table = pe_param.contiguous()
     elif name == "polynomial":
@@ -82,14 +85,18 @@ def _fused_ok(xn: Tensor, num_heads: int) -> bool:
 @torch.library.custom_op("vitpe::attention", mutates_args=())
 def attention(xn: Tensor, wqkv: Tensor, wproj: Tensor, bproj: Tensor, resid: Optional[Tensor], num_heads: int,
               mode: int, grid: int, pe_param: Optional[Tensor], inv_freq: Optional[Tensor], degree: int,
-              per_head: bool) -> Tuple[Tensor, Tensor, Tensor]:
-    """-> (y, a, qkv).  CIFAR geometry: one fused kernel (qkv never leaves the chip, `qkv` is empty);
-    other geometries: qkv Linear (panel GEMM) + the per-(image, head) attention core."""
+              per_head: bool, cos: Optional[Tensor] = None, sin: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+    """-> (y, a, qkv).  CIFAR geometry: one fused kernel (qkv never leaves the chip, `qkv` is empty; bf16 at N = 65,
+    d = 192, hd = 32: the 32x32-tile kernel); other geometries: qkv Linear (panel GEMM) + the per-(image, head) attention
+    core.  cos / sin: caller-supplied rotary tables ([P, hd/2] or [H, P, hd/2]) used instead of the module's own."""
     dt = xn.dtype
     B, N, D = xn.shape
-    t = _pe_tables(mode, grid, pe_param, inv_freq, degree, per_head)
+    t = _pe_tables(mode, grid, pe_param, inv_freq, degree, per_head, cos, sin)
     if _fused_ok(xn, num_heads):
-        a = K.fused_attention_fwd(xn.contiguous(), K.pack_qkv_weights(wqkv.contiguous(), dt, num_heads), num_heads, t)
+        if K.fused_attention_wide_supported(dt, N, D, D // num_heads):
+            a = K.fused_attention_fwd_wide(xn.contiguous(), K.pack_qkv_weights_wide(wqkv.contiguous(), dt, num_heads), num_heads, t)
+        else:
+            a = K.fused_attention_fwd(xn.contiguous(), K.pack_qkv_weights(wqkv.contiguous(), dt, num_heads), num_heads, t)
         qkv = xn.new_empty(0)
     else:
         qkv = K.linear(xn.contiguous().view(B * N, D), _shadow(wqkv, dt), None, epi=L.EPI_BIAS).view(B, N, 3 * D)
@@ -103,20 +110,20 @@ def attention(xn: Tensor, wqkv: Tensor, wproj: Tensor, bproj: Tensor, resid: Opt
 
 
 @attention.register_fake
-def _(xn, wqkv, wproj, bproj, resid, num_heads, mode, grid, pe_param, inv_freq, degree, per_head):
+def _(xn, wqkv, wproj, bproj, resid, num_heads, mode, grid, pe_param, inv_freq, degree, per_head, cos=None, sin=None):
     B, N, D = xn.shape
     return torch.empty_like(xn), torch.empty_like(xn), xn.new_empty(0)
 
 
 def _attn_setup(ctx, inputs, output):
-    xn, wqkv, wproj, bproj, resid, num_heads, mode, grid, pe_param, inv_freq, degree, per_head = inputs
+    xn, wqkv, wproj, bproj, resid, num_heads, mode, grid, pe_param, inv_freq, degree, per_head, cos, sin = inputs
     _, a, qkv = output
-    ctx.save_for_backward(xn, wqkv, wproj, a, qkv, pe_param, inv_freq)
+    ctx.save_for_backward(xn, wqkv, wproj, a, qkv, pe_param, inv_freq, cos, sin)
     ctx.meta = (num_heads, mode, grid, degree, per_head, resid is not None)
 
 
 def _attn_backward(ctx, dy, _da, _dqkv):
-    xn, wqkv, wproj, a, qkv, pe_param, inv_freq = ctx.saved_tensors
+    xn, wqkv, wproj, a, qkv, pe_param, inv_freq, cos, sin = ctx.saved_tensors
     num_heads, mode, grid, degree, per_head, has_resid = ctx.meta
     dt = xn.dtype
     B, N, D = xn.shape
@@ -127,11 +134,14 @@ def _attn_backward(ctx, dy, _da, _dqkv):
     dbproj = torch.zeros(D, dtype=torch.float32, device=dy.device)
     K.gemm_tn(dy2, a.view(B * N, D), dwproj, dbproj)
     # attention backward -> dqkv (+ PE parameter grads)
-    t = _pe_tables(mode, grid, pe_param, inv_freq, degree, per_head)
+    t = _pe_tables(mode, grid, pe_param, inv_freq, degree, per_head, cos, sin)
     dpe = torch.zeros_like(pe_param) if pe_param is not None else None
     name = MODES[mode]
     pe_grads = dict(dtable=dpe if name == "relative" else None, dcoeff=dpe if name == "polynomial" else None,
                     dfreqs=dpe if name == "rope-mixed" else None)
+    if cos is not None and name == "rope-mixed":   # caller-supplied tables are constants: the kernel's frequency gradient is discarded
+        pe_grads["dfreqs"] = torch.zeros(2, num_heads, D // num_heads // 2, dtype=torch.float32, device=xn.device)
+        dpe = None
     if qkv.numel() == 0:
         dqkv = K.fused_attention_bwd(xn.contiguous(), K.pack_qkv_weights(wqkv.contiguous(), dt, num_heads),
                                      da.view(B, N, D), num_heads, t, **pe_grads)
@@ -141,7 +151,7 @@ def _attn_backward(ctx, dy, _da, _dqkv):
     dxn = K.linear(dq2, _shadow_t(wqkv, dt), None, epi=L.EPI_BIAS).view(B, N, D)
     dwqkv = torch.zeros_like(wqkv)
     K.gemm_tn(dq2, xn.contiguous().view(B * N, D), dwqkv, None)
-    return (dxn, dwqkv, dwproj, dbproj, dy if has_resid else None, None, None, None, dpe, None, None, None)
+    return (dxn, dwqkv, dwproj, dbproj, dy if has_resid else None, None, None, None, dpe, None, None, None, None, None)
 
 
 attention.register_autograd(_attn_backward, setup_context=_attn_setup)

@@ -71,12 +71,33 @@ class Attention(nn.Module):
     def forward(self, x, freqs_cis=None, resid=None):
         require_device(x)
         B, N, C = x.shape
-        # RoPE rotates only when the caller passes the (cos, sin) tables (reference vit.py:51);
-        # the fused kernel regenerates them on the device from the module's own parameters.
+        # RoPE rotates only when the caller passes freqs_cis (reference vit.py:51).  VisionTransformer.forward_features
+        # passes a marker and the kernel builds the tables on the device from the module's own parameters (which keeps
+        # the RoPE-mixed frequencies trainable); a caller's own (cos, sin) tensors are used AS GIVEN (vit.py:51-64).
         mode, pe_param, inv_freq, degree, per_head = _pe_args(self.pos_encoding, freqs_cis is not None)
         grid = int(math.sqrt(N - 1))
+        cos = sin = None
+        if isinstance(freqs_cis, (tuple, list)) and len(freqs_cis) == 2 and all(torch.is_tensor(t) for t in freqs_cis):
+            cos, sin = freqs_cis
+            if not (cos.is_cuda and sin.is_cuda):
+                raise VitpeError("vitpe: HIP device tensor required (got a CPU tensor; there is no CPU fallback)")
+            if mode in (_MODE["relative"], _MODE["polynomial"]):
+                raise NotImplementedError("vitpe Attention: rotary tables together with an additive bias encoding")
+            if cos.shape != sin.shape or cos.dim() not in (2, 3) or tuple(cos.shape[-2:]) != (N - 1, self.head_dim // 2) \
+                    or (cos.dim() == 3 and cos.shape[0] != self.num_heads):
+                # (reshape_for_broadcast's error, reference rope_utils.py:39-66)
+                raise ValueError(f"Unexpected shape for freqs_cis: {tuple(cos.shape)}")
+            if cos.requires_grad or sin.requires_grad:
+                # autograd-tracked tables are RoPEMixed.get_freqs_cis of the module's own frequencies (reference
+                # vit.py:262-266): the kernel rebuilds them from the parameter, so the gradient reaches it as the
+                # reference's autograd would; differentiable tables from anywhere else are not supported
+                if not isinstance(self.pos_encoding, RoPEMixed) or cos.dim() != 3:
+                    raise NotImplementedError("vitpe Attention: caller-supplied (cos, sin) tables that require grad")
+                cos = sin = None
+            else:
+                mode, pe_param, inv_freq = (_MODE["rope-axial"] if cos.dim() == 2 else _MODE["rope-mixed"]), None, None
         y, _, _ = torch.ops.vitpe.attention(x, self.qkv.weight, self.proj.weight, self.proj.bias, resid, self.num_heads,
-                                         mode, grid, pe_param, inv_freq, degree, per_head)
+                                         mode, grid, pe_param, inv_freq, degree, per_head, cos, sin)
         return y
 
     def set_pos_encoding(self, pos_encoding):
