@@ -856,7 +856,7 @@ def test_fused_attention_fwd_wide(K, mode, B, ln):
     w = K.pack_qkv_weights_wide(dev(wqkv), torch.bfloat16, H)
     if ln:
         xr = dev(x * 1.7 + 0.4, torch.bfloat16)
-        gam, bet = dev(rnd(D, seed=5) + 1.2), dev(rnd(D, seed=6))
+        gam, bet = dev(1 + 0.1 * rnd(D, seed=5)), dev(0.1 * rnd(D, seed=6))
         xn, mean, rstd = K.layernorm_fwd(xr, gam, bet)
         xo = torch.empty_like(xr)
         out = K.fused_attention_fwd_wide(xr, w, H, t, ln=(gam, bet, mean, rstd), xn_out=xo)

@@ -634,9 +634,13 @@ VITPE_DEV void t2_unpack_pair_f16(const Chunk16& v, f32x4& o0, f32x4& o1) {
 #pragma unroll
   for (int w2 = 0; w2 < 2; ++w2) {
     const auto r = __builtin_amdgcn_permlane16_swap(v[w2], v[2 + w2], false, false);
-    const t2_half2 a = __builtin_bit_cast(t2_half2, r[0]), b = __builtin_bit_cast(t2_half2, r[1]);
-    o0[2 * w2] = (float)a[0]; o0[2 * w2 + 1] = (float)a[1];
-    o1[2 * w2] = (float)b[0]; o1[2 * w2 + 1] = (float)b[1];
+    // (scalar halves on purpose: with a 2 x half vector cast of the two results hipcc 7.2 multiplied BOTH tiles by the
+    //  first result's values -- the second result of the swap was dead in the emitted code)
+    const uint32_t ra = r[0], rb = r[1];
+    o0[2 * w2] = (float)__builtin_bit_cast(_Float16, (unsigned short)(ra & 0xffffu));
+    o0[2 * w2 + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(ra >> 16));
+    o1[2 * w2] = (float)__builtin_bit_cast(_Float16, (unsigned short)(rb & 0xffffu));
+    o1[2 * w2 + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(rb >> 16));
   }
 }
 

@@ -269,7 +269,7 @@ def block_tail2_bwd(dy, gp, w2t_pk, w1t_pk, x_mid, mean2, rstd2, gamma, dgamma, 
     assert wpt_pk.numel() == D * D and dy.dtype == w2t_pk.dtype == w1t_pk.dtype == x_mid.dtype == wpt_pk.dtype
     assert gp.dtype == torch.float16   # (block_tail2_fwd keeps gelu'(u) as IEEE half)
     _f32(gamma, "gamma"), _f32(dgamma, "dgamma"), _f32(dbeta, "dbeta"), _f32(mean2, "mean2"), _f32(rstd2, "rstd2")
-    du = du if du is not None else torch.empty(gp.shape, dtype=dy_out.dtype, device=dy_out.device)
+    du = du if du is not None else torch.empty(gp.shape, dtype=dy.dtype, device=dy.device)
     out = out if out is not None else torch.empty_like(dy)
     da = da if da is not None else torch.empty_like(dy)
     check(lib().vitpe_block_tail2_bwd(dtype_code(dy.dtype), ptr(dy), ptr(gp), ptr(w2t_pk), ptr(w1t_pk), ptr(x_mid), ptr(mean2),
