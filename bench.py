@@ -53,6 +53,10 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-kernel-probes", action="store_true", help="skip the per-kernel roofline launches")
+    ap.add_argument("--rccl-channels", type=int, default=int(os.environ.get("VITPE_RCCL_CHANNELS", "0")),
+                    help="cap RCCL at this many channels (NCCL_MAX_NCHANNELS; each channel is a workgroup that competes with "
+                         "the one-workgroup-per-CU compute kernels for the CUs while the lower half of the backward runs); "
+                         "0 = RCCL's default, or whatever NCCL_MAX_NCHANNELS the caller exported")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU ranks over gloo with a stand-in step: checks launcher, rendezvous and the JSON contract only")
     return ap.parse_args(argv)
@@ -222,6 +226,10 @@ def main(argv=None):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dry = args.dry_run
+    if args.rccl_channels > 0:     # before the communicator exists
+        os.environ["NCCL_MAX_NCHANNELS"] = str(args.rccl_channels)
+        os.environ["NCCL_MIN_NCHANNELS"] = str(min(args.rccl_channels, int(os.environ.get("NCCL_MIN_NCHANNELS", "1"))))
+    rccl_channels = int(os.environ["NCCL_MAX_NCHANNELS"]) if os.environ.get("NCCL_MAX_NCHANNELS") else None
     imnet = args.config == "imnet"
     geom = dict(img_size=224, patch_size=16, embed_dim=768, depth=12, num_heads=12) if imnet else \
         dict(img_size=32, patch_size=4, embed_dim=192, depth=6, num_heads=6)
@@ -288,6 +296,8 @@ def main(argv=None):
             nocomm = timed_steps(args.steps, exchange=False)     # the same step without the exchange (replicas diverge)
             exposed_ms = max(0.0, 1e3 * (elapsed - nocomm) / args.steps)
             overlap_frac = round(min(1.0, max(0.0, 1.0 - exposed_ms / comm_ms)), 4) if comm_ms > 0 else None
+            if getattr(eng, "ddp_graph", False):
+                overlap_frac = None      # the exchange is inside the replayed graph: it cannot be switched off to measure
             comm_ms = round(comm_ms, 4)
 
     peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
@@ -315,6 +325,8 @@ def main(argv=None):
                        "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
                        "final_loss_mean": round(loss[0] / max(args.steps + args.warmup, 1), 4)},
             "n_ranks_seen": n_ranks_seen, "comm_ms": comm_ms, "overlap_frac": overlap_frac,
+            "rccl_max_channels": rccl_channels,      # None = RCCL's own default
+            "ddp_graph": (bool(getattr(eng, "ddp_graph", False)) if world > 1 else None),   # all-reduces captured in the step's graph
         }
         if dry:
             line["dry_run"] = True
@@ -325,7 +337,7 @@ def main(argv=None):
             line["roofline"].update({k: v for k, v in head.items() if k not in line["roofline"] and k != "name"})
             line["other_kernels"] = [r for r in recs if r["name"] != "attn_fwd"]
         if world == 1 and not args.no_cpu_baseline and not dry:
-            line["cpu_baseline"] = (cpu_baseline(args.pos_encoding, steps=2, warmup=1, bs=8, cfg_kw=geom, img=img) if imnet
+            line["cpu_baseline"] = (cpu_baseline(args.pos_encoding, steps=6, warmup=1, bs=8, cfg_kw=geom, img=img) if imnet
                                     else cpu_baseline(args.pos_encoding))
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -253,6 +253,19 @@ def test_bench_starts_its_own_ranks_and_also_runs_under_the_launcher(launcher):
         assert key in ln
 
 
+def test_bench_eight_ranks_dry_run_and_rccl_channel_budget():
+    """`python bench.py --gpus 8 --dry-run` (the driver's largest configuration, on CPU ranks over gloo): eight ranks
+    rendezvous, the collective itself counts eight, rank 0 prints one line with the weak-scaling bookkeeping; a channel
+    budget for RCCL (--rccl-channels) reaches the environment the communicator is created in and is reported."""
+    rc, lines, err = _run_bench(["--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run", "--rccl-channels", "4"])
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1
+    ln = lines[0]
+    assert ln["n_gpus"] == 8 and ln["n_ranks_seen"] == 8 and ln["scaling"] == "weak"
+    assert ln["config"]["parallelism"] == "dp8" and ln["config"]["global_batch"] == 8 * ln["config"]["per_gpu_batch"] == 4096
+    assert ln["rccl_max_channels"] == 4 and "ddp_graph" in ln
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     rc, lines, err = _run_bench(["--gpus", "2", "--dry-run"], env_extra={"WORLD_SIZE": "1", "RANK": "0"})
     assert rc != 0 and not lines

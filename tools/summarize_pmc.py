@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Counter passes of tools/gpu_session.sh pmc  ->  profiles/rNN_pmc.json in the keyed form bench.py reads.
 
-    python3 tools/summarize_pmc.py <gpurun_out> <tag> [--round 02] [--batch 512] [--pos_encoding rope-axial] [--dtype bf16]
+    python3 tools/summarize_pmc.py <gpurun_out> <tag> [--round 03] [--batch 512] [--pos_encoding rope-axial] [--dtype bf16]
 
 Reads <out>/<tag>_pmc_{fetch,write,sq}/**/*_counter_collection.csv (separate rocprofv3 --pmc passes over
 `bench.py --no-kernel-probes`, i.e. the captured training step itself), takes the MEDIAN per kernel over its launches,
@@ -25,7 +25,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # probe name (bench.py / engine.kernel_probes) -> substrings; the FIRST kernel whose name contains all of them is used
 PROBES = {
-    "attn_fwd": ["attn_fwd_kernel"],
+    "attn_fwd": ["attn32_fwd_kernel"],      # the 32x32-tile forward (csrc/attn32.hip); the 16x16-tile kernel: FALLBACK
     "attn_bwd": ["attn_bwd"],
     "block_tail_fwd": ["block_tail2_fwd_kernel"],
     "block_tail_bwd": ["block_tail2_bwd_kernel<false>"],
@@ -48,6 +48,7 @@ PROBES = {
 }
 # first-generation block-tail kernels (when the second generation does not run): mangled vs demangled spelling
 FALLBACK = {
+    "attn_fwd": [["attn_fwd_kernel"]],
     "dgrad_qkv_ln1_bwd": [["gemm_panel_kernel"]],
     "block_tail_fwd": [["mlp_fwd_kernelIDF16bLi0E"], ["mlp_fwd_kernel<", "0, true"]],
     "block_tail_bwd": [["block_tail2_bwd_kernel"], ["vitpe::mlp_fwd_kernel<"], ["mlp_fwd_kernelIDF16bLi1E"]],
@@ -79,7 +80,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("root")
     ap.add_argument("tag")
-    ap.add_argument("--round", default="02")
+    ap.add_argument("--round", default="03")
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--pos_encoding", default="rope-axial")
     ap.add_argument("--dtype", default="bf16")

@@ -187,8 +187,7 @@ def test(engine, loader):
             seen += n_global
         else:
             images, labels = item
-            engine.forward_only(images)
-            engine.labels.copy_(labels)
+            engine.forward_only(images, labels)     # (pads a short batch: images AND labels, like the resident path)
             engine.eval_loss(images.shape[0], acc, images.shape[0] * engine.world)
             seen += images.shape[0] * engine.world
     if engine.world > 1:
@@ -209,6 +208,8 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     rank, world, _ = ddp.init_from_env(device=device)
+    if args.batch_size % world != 0:   # (epoch_global_batches cuts every global batch into `world` equal shares)
+        raise SystemExit(f"--batch_size {args.batch_size} is not divisible by the world size {world}")
     lo, hi = ddp.shard_bounds(args.batch_size, rank, world)
     per_rank = hi - lo
     info = DATASETS[args.dataset]

@@ -495,6 +495,9 @@ static int wgrad_group_launch(int dtype, const void* problems, int nprob, unsign
   }
   bool lnx = false;
   for (int i = 0; i < np; ++i) lnx = lnx || a.p[i].xop != 0;
+  // (the census instantiation exists for bf16 operands without the LayerNorm X operand only: anything else would silently
+  //  accumulate gradients of the wrong operands)
+  if (census != nullptr) VITPE_REQUIRE(!lnx && dtype == 1);
   if (census != nullptr) hipLaunchKernelGGL((wgrad_group_kernel<bf16, true, false>), dim3(grid), dim3(768), 0, stream, a);
   else if (dtype == 1 && lnx) hipLaunchKernelGGL((wgrad_group_kernel<bf16, false, true>), dim3(grid), dim3(768), 0, stream, a);
   else if (dtype == 1) hipLaunchKernelGGL((wgrad_group_kernel<bf16, false, false>), dim3(grid), dim3(768), 0, stream, a);

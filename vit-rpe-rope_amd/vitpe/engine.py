@@ -75,6 +75,7 @@ class TrainEngine:
         self.attn_fused = K.fused_attention_supported(self.T, self.N, self.D, self.D // self.H)
         if not self.attn_fused and not K.attention_core_supported(self.T, self.N, self.D // self.H):
             raise L.VitpeError(f"no attention kernel for N={self.N}, D={self.D}, hd={self.D // self.H}")
+        self._save_hidden = True
         # the 32x32-tile forward kernel (csrc/attn32.hip) for the benchmark geometry; VITPE_ATTN_WIDE=0: the 16x16-tile one
         self.attn_wide = (self.attn_fused and K.fused_attention_wide_supported(self.T, self.N, self.D, self.D // self.H)
                           and os.environ.get("VITPE_ATTN_WIDE", "1") == "1")
@@ -99,6 +100,11 @@ class TrainEngine:
         self.bucket_off = self._off[id(next(self.model.blocks[self.split_layer].parameters()))] \
             if self.Lyr >= 2 else 0
         self.overlap_comm = self.world > 1 and self.Lyr >= 2
+        # VITPE_DDP_GRAPH=1: capture the two bucket all-reduces INSIDE the step's HIP graph (bucket 1 on a forked stream
+        # beside the lower half of the backward): a step is then ONE replay instead of three replays stitched from the
+        # host.  Off by default: RCCL capture has not run on hardware yet (no multi-GPU lease this round either) -- the
+        # stitched path only uses plain torch.distributed calls.  A failed capture falls back to it.
+        self.ddp_graph = self.world > 1 and os.environ.get("VITPE_DDP_GRAPH", "0") == "1"
         self.graph_fb = self.graph_fb2 = self.graph_opt = None
         self.steps_done = 0
 
@@ -382,10 +388,12 @@ class TrainEngine:
             K.head_fwd(self.x[-1], mdl.norm.weight.data, mdl.norm.bias.data, mdl.head.weight.data, mdl.head.bias.data,
                        mdl.norm.eps, save=True, logits=self.logits, ws=self.head_ws)
 
-    def _block_tail_fwd(self, l, blk, a, nxt):
+    def _block_tail_fwd(self, l, blk, a, nxt, save=None):
+        """save: keep gelu'(u) and gelu(u) for the backward (None: what the running _forward was asked for)."""
         M, D = self.M, self.D
         eps_next = self.model.blocks[min(l + 1, self.Lyr - 1)].norm1.eps
-        save = getattr(self, "_save_hidden", True)
+        if save is None:
+            save = self._save_hidden
         if self.tail2:   # wave-per-token-tile kernel on fragment-packed weights; keeps gelu'(u) in a["u"] instead of u
             K.block_tail2_fwd(a["a"].view(M, D), self.x[l].view(M, D), self.Fr(blk.attn.proj.weight),
                               blk.attn.proj.bias.data, blk.norm2.weight.data, blk.norm2.bias.data,
@@ -634,6 +642,33 @@ class TrainEngine:
         self.flat_g.zero_()
         self.refresh_shadows()
         torch.cuda.synchronize()
+        if self.ddp_graph:
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._fwd_train(); self._loss()
+                    if self.overlap_comm:
+                        self._backward("upper")
+                        side, main = torch.cuda.Stream(), torch.cuda.current_stream()
+                        side.wait_stream(main)                        # fork: bucket 1 (head + upper layers) ...
+                        with torch.cuda.stream(side):
+                            dist.all_reduce(self.flat_g[self.bucket_off:], op=dist.ReduceOp.SUM, group=self.pg)
+                        self._backward("lower")                       # ... beside the lower layers' backward
+                        dist.all_reduce(self.flat_g[:self.bucket_off], op=dist.ReduceOp.SUM, group=self.pg)
+                        main.wait_stream(side)                        # join
+                    else:
+                        self._backward()
+                        self._allreduce()
+                    self._optimizer()
+                torch.cuda.synchronize()
+                self.graph_fb, self.graph_fb2, self.graph_opt = g, None, None
+                return
+            except Exception as exc:   # noqa: BLE001  (communicator does not support capture here: the stitched path below)
+                import warnings
+                warnings.warn(f"VITPE_DDP_GRAPH: capturing the all-reduces failed ({exc!r}); using the host-stitched step")
+                self.ddp_graph = False
+                torch.cuda.synchronize()
+                self.flat_g.zero_()
         # thread_local: a communicator watchdog thread touching the device must not invalidate the capture
         self.graph_fb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_fb, capture_error_mode="thread_local"):
@@ -741,7 +776,7 @@ class TrainEngine:
             if self.graph_fb is None:
                 self.capture()
             self.graph_fb.replay()
-            if self.world > 1:
+            if self.world > 1 and not self.ddp_graph:      # (ddp_graph: the exchange is part of the replayed graph)
                 if self.overlap_comm:
                     # bucket 1 (upper layers + head) is exchanged while the lower layers' backward runs
                     w1 = w2 = None
@@ -765,11 +800,12 @@ class TrainEngine:
         """forward + loss + backward on the resident batch without the optimizer (tests / parity)."""
         self._fwd_train(); self._loss(tick=False); self._backward()
 
-    def forward_only(self, images: torch.Tensor) -> torch.Tensor:
-        """Logits [n, classes] of `images` [n <= B, C, S, S] (eager forward on the same kernels)."""
+    def forward_only(self, images: torch.Tensor, labels: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Logits [n, classes] of `images` [n <= B, C, S, S] (eager forward on the same kernels); `labels` [n], when
+        given, are loaded (and padded) with them for a following eval_loss."""
         if self.dataset is not None:
             raise L.VitpeError("a resident dataset is attached: use forward_indexed (or attach_dataset(None))")
-        n = self._load_batch(images, None)
+        n = self._load_batch(images, labels)
         self._forward()
         return self.logits[:n]
 
@@ -821,7 +857,7 @@ class TrainEngine:
             def tail_f(l):
                 blk, a = mdl.blocks[l], self.act[l]
                 nxt = (self.act[l + 1]["m1"], self.act[l + 1]["r1"]) if l + 1 < self.Lyr else None
-                return lambda: self._block_tail_fwd(l, blk, a, nxt)
+                return lambda: self._block_tail_fwd(l, blk, a, nxt, save=True)   # the TRAINING instantiation, whatever ran last
             def tail_b(l):
                 blk, a = mdl.blocks[l], self.act[l]
                 return lambda: self._block_tail_bwd(l, blk, a)
@@ -867,7 +903,11 @@ class TrainEngine:
         """acc[0] += (sum of the cross-entropy of rows [0, n) of the current logits vs self.labels) / n_global (this
         rank's part of the batch mean, reference train.py:146-149; n_global defaults to n), acc[1] += #correct.
         Device-side; leaves the training scalars untouched."""
-        ctl = torch.tensor([0.0, 1.0 / max(n_global or n, 1), float(n), 0.0], device=self.dev)
+        key = (n, n_global or n)
+        if getattr(self, "_eval_ctl_key", None) != key:   # (one host -> device copy per distinct batch shape, not per batch)
+            self._eval_ctl = torch.tensor([0.0, 1.0 / max(n_global or n, 1), float(n), 0.0], device=self.dev)
+            self._eval_ctl_key = key
+        ctl = self._eval_ctl
         K.cross_entropy_ctl(self.logits, self.labels, ctl, dlogits=None, out2=self.out2, metric_acc=acc)
 
     def read_metrics(self, reset=True):
