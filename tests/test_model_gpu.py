@@ -159,12 +159,13 @@ def test_attention_uses_the_callers_rotary_tables():
         N, hd, B = 65, D // H, 3
         att = Attention(D, num_heads=H)
         att.set_pos_encoding(pe.RoPEAxial(hd, 100.0))
-        with torch.no_grad():
-            att.qkv.weight.copy_(O.closed_form_tensor("attn.qkv.weight", (3 * D, D)) * 4)
-            att.proj.weight.copy_(O.closed_form_tensor("attn.proj.weight", (D, D)) * 4)
-            att.proj.bias.copy_(O.closed_form_tensor("attn.proj.bias", (D,)))
+        gen = torch.Generator().manual_seed(5)
+        with torch.no_grad():   # (random weights: the closed-form sin() fixtures cancel in the projection, which bf16 cannot follow)
+            att.qkv.weight.copy_(torch.randn(3 * D, D, generator=gen) * 0.25)
+            att.proj.weight.copy_(torch.randn(D, D, generator=gen) * 0.1)
+            att.proj.bias.copy_(torch.randn(D, generator=gen) * 0.1)
         att.cuda()
-        x = O.closed_form_tensor("attn.x", (B, N, D)) * (20 if dt == torch.float32 else 4)   # (bf16: logits of a few units, or one-hot rows flip on rounding)
+        x = torch.randn(B, N, D, generator=gen)
         ang = torch.linspace(0.0, 2.5, (N - 1) * (hd // 2)).reshape(N - 1, hd // 2) ** 1.3        # not the module's angles
         for tabs in (ang, torch.stack([ang * (1 + 0.1 * h) for h in range(H)])):                   # [P, hd/2] and [H, P, hd/2]
             cos, sin = torch.cos(tabs), torch.sin(tabs)

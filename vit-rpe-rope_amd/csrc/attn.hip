@@ -515,7 +515,8 @@ VITPE_DEV void stage_rows_plain(const T* src, T* dst, int ld, int N, int tid) {
   for (int it = 0; it < ITERS; ++it) *reinterpret_cast<Chunk16*>(dst + (r0 + it * RPP) * ld + cc * CHN) = v[it];
 }
 
-template <int HD, int D, int MT, int KM, int NTOK, int IPW, bool LNF, bool MIXED>
+// PDEG (polynomial mode): highest degree this instantiation accumulates (3: the reference's default, or MAXDEG)
+template <int HD, int D, int MT, int KM, int NTOK, int IPW, bool LNF, bool MIXED, int PDEG = 7>
 __global__ __launch_bounds__(64 * (D / HD) * IPW, 3) void attn_bwd_reg_kernel(AttnArgs a) {
   using T = bf16;
   using C = AttnCfg<T, HD, D, MT, 1, NTOK>;
@@ -703,6 +704,13 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, 3) void attn_bwd_reg_kernel(At
     if (ok) *reinterpret_cast<Chunk16*>(rowp + f0) = (Chunk16){lo[0], lo[1], hi[0], hi[1]};
   };
 
+  // Polynomial-RPE coefficient gradient, d coeff[k] = sum_ij dS[i][j] dist(i, j)^k over patch pairs (positional_encoding.py
+  // :127-171 backwards): ONE set of PDEG + 1 per-lane accumulators for the whole wave, reduced once at the end.  (The
+  // first version ran a MAXDEG-long power loop with a run-time degree test per element and a wave reduction per tile:
+  // ~26 VALU per logit, 57 spilled registers -- the mode's backward took 75 us against 34.)
+  float cacc[PDEG + 1];
+#pragma unroll
+  for (int k = 0; k <= PDEG; ++k) cacc[k] = 0.f;
   // ---- step 1: query tiles on the swapped tiles --------------------------------------------------------------
 #pragma unroll
   for (int it = 0; it < MT; ++it) {
@@ -711,17 +719,29 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, 3) void attn_bwd_reg_kernel(At
     const Frag<T> dof = dof_load(it), qfi = qf_load(it);
     f32x4 s[MT], dp[MT];
     float m = -1e30f;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    // polynomial bias by L1 grid distance: the packed coordinates of this lane's query (once per tile) and of its four
+    // keys (one 16-B LDS read per key tile) instead of two coordinate reads per logit; class-token row / column = 0
+    const unsigned xyi = (KM == KM_POLY) ? reinterpret_cast<const unsigned*>(s_coef + C::H * C::PBLD)[i] : 0u;
+    const float* const ptab = s_coef + (a.coeff_per_head ? h : 0) * C::PBLD;
+    const bool qcls = (it == 0) && (c == 0);
 #pragma unroll
     for (int jt = 0; jt < MT; ++jt) {
       s[jt] = z4;
       mma(kf[jt], qfi, s[jt]);
       dp[jt] = z4;
       mma(vkf[jt], dof, dp[jt]);
+      const u32x4 xyj = (KM == KM_POLY) ? *reinterpret_cast<const u32x4*>(s_coef + C::H * C::PBLD + 16 * jt + 4 * g) : (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = 16 * jt + 4 * g + r;
         float v = s[jt][r];
-        if (KM == KM_RELATIVE || KM == KM_POLY) v += pe_bias2<C, KM>(a, s_tab, s_coef, h, i, j, N);
+        if (KM == KM_RELATIVE) v += pe_bias2<C, KM>(a, s_tab, s_coef, h, i, j, N);
+        if (KM == KM_POLY) {
+          const float bv = ptab[__builtin_amdgcn_sad_u8(xyi, xyj[r], 0u)];
+          const bool cls = qcls || (jt == 0 && r == 0 && g == 0);
+          v += cls ? 0.f : bv;
+        }
         if (jt == MT - 1) v = (j < N) ? v : -1e30f;
         s[jt][r] = v;
         m = fmaxf(m, v);
@@ -742,12 +762,17 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, 3) void attn_bwd_reg_kernel(At
       for (int r = 0; r < 4; ++r) { s[jt][r] *= inv; dl += s[jt][r] * dp[jt][r]; }
     dl = xg_sum(dl);
     if (g == 0) { lse_w[i] = m + __builtin_amdgcn_logf(l); del_w[i] = dl; }   // v_log_f32 = log2
-    float cacc[C::MAXDEG + 1];
-#pragma unroll
-    for (int k = 0; k <= C::MAXDEG; ++k) cacc[k] = 0.f;
     const bool qvalid = (it < MT - 1) || (i < N);
+    float tacc[PDEG + 1];                  // this tile's contribution (one query per lane: the class-token mask is per tile)
 #pragma unroll
-    for (int jt = 0; jt < MT; ++jt)
+    for (int k = 0; k <= PDEG; ++k) tacc[k] = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt) {
+      // (fenced per key tile: left alone the scheduler computes the distances and their powers of all twenty logits
+      //  ahead of the dS values -- sixty live registers, 184 spilled)
+      if (KM == KM_POLY) __builtin_amdgcn_sched_barrier(0);
+      // packed (x | y << 8) grid coordinates of this lane's four keys: one 16-B LDS read
+      const u32x4 xyj = (KM == KM_POLY) ? *reinterpret_cast<const u32x4*>(s_coef + C::H * C::PBLD + 16 * jt + 4 * g) : (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = 16 * jt + 4 * g + r;
@@ -755,14 +780,24 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, 3) void attn_bwd_reg_kernel(At
         const float ds = valid ? s[jt][r] * (dp[jt][r] - dl) : 0.f;
         dp[jt][r] = ds;
         if (KM == KM_POLY) {
-          if (valid && i >= 1 && j >= 1) {
-            const float x = (float)pe_l1<C>(s_coef, i, j);
-            float pw = 1.f;
+          // the class-token COLUMN is key 0 = element (jt 0, g 0, r 0) only; the class-token ROW is masked per tile below
+          const float dsk = (jt == 0 && r == 0) ? (g == 0 ? 0.f : ds) : ds;
+          const float x = (float)__builtin_amdgcn_sad_u8(xyi, xyj[r], 0u);
+          float pw = x;
+          tacc[0] += dsk;
 #pragma unroll
-            for (int k = 0; k <= C::MAXDEG; ++k) { if (k <= a.degree) cacc[k] += ds * pw; pw *= x; }
-          }
+          for (int k = 1; k <= PDEG; ++k) { tacc[k] = fmaf(dsk, pw, tacc[k]); if (k < PDEG) pw *= x; }
         }
       }
+    }
+    if (KM == KM_POLY) {
+      const float qm = (it == 0 && c == 0) ? 0.f : 1.f;      // query 0 is the class token: its row of the bias is zero
+#pragma unroll
+      for (int k = 0; k <= PDEG; ++k) {
+        cacc[k] = fmaf(qm, tacc[k], cacc[k]);
+        asm volatile("" : "+v"(cacc[k]));   // final HERE: left alone the compiler sinks the whole accumulation of all five tiles
+      }                                     // behind the loop (its only use) and parks the hundred dS values in scratch meanwhile
+    }
     if (KM == KM_RELATIVE) {
 #pragma unroll
       for (int jt = 0; jt < MT; ++jt) {
@@ -774,14 +809,6 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, 3) void attn_bwd_reg_kernel(At
           if (c >= 1 && idx0 - 16 >= 0 && idx0 - 16 <= 2 * N - 2) atomicAdd(&dtab_i[h * C::TABLD + idx0 - 16], d1);
         }
       }
-    }
-    if (KM == KM_POLY) {
-#pragma unroll
-      for (int k = 0; k <= C::MAXDEG; ++k)
-        if (k <= a.degree) {
-          const float t = wave_sum(cacc[k]);
-          if (lane == 0) atomicAdd(&dcoef_i[(a.coeff_per_head ? h : 0) * (C::MAXDEG + 1) + k], t);
-        }
     }
     // dQrot^T[d][i] / scale = sum_j K^T[d][j] dS^T[j][i]
     f32x4 dqa[NT] = {z4, z4};
@@ -808,6 +835,14 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, 3) void attn_bwd_reg_kernel(At
     store_pair(dqg + (size_t)i * 3 * D, dqa[0] * a.scale, dqa[1] * a.scale, qvalid);
   }
 
+  if (KM == KM_POLY) {
+#pragma unroll
+    for (int k = 0; k <= PDEG; ++k)
+      if (k <= a.degree) {
+        const float t = wave_sum(cacc[k]);
+        if (lane == 0) atomicAdd(&dcoef_i[(a.coeff_per_head ? h : 0) * (C::MAXDEG + 1) + k], t);
+      }
+  }
   // ---- Q^T and dO^T operands for dK / dV (K^T is dead now) -------------------------------------------------------
   Frag<T> qtf[NT][SC], dotf[NT][SC];
   __builtin_amdgcn_sched_barrier(0);
@@ -827,6 +862,9 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, 3) void attn_bwd_reg_kernel(At
     __builtin_amdgcn_sched_barrier(0);
     const int j = 16 * jt + c;
     const bool kvalid = (jt < MT - 1) || (j < N);
+    const unsigned xyk = (KM == KM_POLY) ? reinterpret_cast<const unsigned*>(s_coef + C::H * C::PBLD)[j] : 0u;
+    const float* const ptab2 = s_coef + (a.coeff_per_head ? h : 0) * C::PBLD;
+    const bool kcls = (jt == 0) && (c == 0);
     f32x4 p[MT], ds[MT];
 #pragma unroll
     for (int it = 0; it < MT; ++it) {
@@ -837,11 +875,18 @@ __global__ __launch_bounds__(64 * (D / HD) * IPW, 3) void attn_bwd_reg_kernel(At
       mma(dof, vkf[jt], ds[it]);           // dP[query][key]
       const f32x4 lse = *reinterpret_cast<const f32x4*>(&lse_w[16 * it + 4 * g]);
       const f32x4 dlv = *reinterpret_cast<const f32x4*>(&del_w[16 * it + 4 * g]);
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      const u32x4 xyq = (KM == KM_POLY) ? *reinterpret_cast<const u32x4*>(s_coef + C::H * C::PBLD + 16 * it + 4 * g) : (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = 16 * it + 4 * g + r;
         float sv = p[it][r];
-        if (KM == KM_RELATIVE || KM == KM_POLY) sv += pe_bias2<C, KM>(a, s_tab, s_coef, h, i, j, N);
+        if (KM == KM_RELATIVE) sv += pe_bias2<C, KM>(a, s_tab, s_coef, h, i, j, N);
+        if (KM == KM_POLY) {
+          const float bv = ptab2[__builtin_amdgcn_sad_u8(xyk, xyq[r], 0u)];
+          const bool cls = kcls || (it == 0 && r == 0 && g == 0);
+          sv += cls ? 0.f : bv;
+        }
         const bool valid = kvalid && ((it < MT - 1) || (i < N));
         const float pv = valid ? __builtin_amdgcn_exp2f(sv - lse[r]) : 0.f;
         p[it][r] = pv;
@@ -1272,6 +1317,13 @@ static int launch_attn3(bool bwd, const AttnArgs& a, hipStream_t s) {
         if (a.mode == PE_ROPE_MIXED) {
           if (ln) hipLaunchKernelGGL((attn_bwd_reg_kernel<HD, D, MT, KM, NTOK, 2, true, true>), grid, block, 0, s, a);
           else hipLaunchKernelGGL((attn_bwd_reg_kernel<HD, D, MT, KM, NTOK, 2, false, true>), grid, block, 0, s, a);
+          VITPE_CHECK_LAUNCH();
+        }
+      }
+      if constexpr (KM == KM_POLY) {
+        if (a.degree <= 3) {   // the reference's default degree: four accumulators instead of eight
+          if (ln) hipLaunchKernelGGL((attn_bwd_reg_kernel<HD, D, MT, KM, NTOK, 2, true, false, 3>), grid, block, 0, s, a);
+          else hipLaunchKernelGGL((attn_bwd_reg_kernel<HD, D, MT, KM, NTOK, 2, false, false, 3>), grid, block, 0, s, a);
           VITPE_CHECK_LAUNCH();
         }
       }

@@ -476,13 +476,34 @@ __global__ __launch_bounds__(768, 3) void attn32_fwd_kernel(AttnArgs a) {
     mma32(kf[0][1], qf[qt][1], s0);
     mma32(kf[1][1], qf[qt][1], s1);
     float sodd = so[0];                              // every row of that tile is the odd key
-    if (KM == KM_RELATIVE || KM == KM_POLY) {
+    if (KM == KM_RELATIVE) {
       sodd += pe_bias2<C, KM>(a, s_tab, s_coef, h, i, 64, N);
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int j = (q & 3) + 8 * (q >> 2) + 4 * hh;
         s0[q] += pe_bias2<C, KM>(a, s_tab, s_coef, h, i, j, N);
         s1[q] += pe_bias2<C, KM>(a, s_tab, s_coef, h, i, 32 + j, N);
+      }
+    }
+    if (KM == KM_POLY) {
+      // bias tabulated by L1 grid distance: the packed coordinates of this lane's query once, of its keys four at a time
+      // (16-B LDS reads), one v_sad_u8 + one table read per logit; class-token row / column = 0 (positional_encoding.py:165-169)
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      const unsigned* const xy = reinterpret_cast<const unsigned*>(s_coef + C::H * C::PBLD);
+      const float* const ptab = s_coef + (a.coeff_per_head ? h : 0) * C::PBLD;
+      const unsigned xyi = xy[i];
+      const bool qcls = (qt == 0) && (r == 0);
+      sodd += qcls ? 0.f : ptab[__builtin_amdgcn_sad_u8(xyi, xy[64], 0u)];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const u32x4 xa = *reinterpret_cast<const u32x4*>(xy + 8 * q4 + 4 * hh), xb = *reinterpret_cast<const u32x4*>(xy + 32 + 8 * q4 + 4 * hh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float b0 = ptab[__builtin_amdgcn_sad_u8(xyi, xa[e], 0u)], b1 = ptab[__builtin_amdgcn_sad_u8(xyi, xb[e], 0u)];
+          const bool kcls = (q4 == 0) && (e == 0) && (hh == 0);            // key 0 = the class token
+          s0[4 * q4 + e] += (qcls || kcls) ? 0.f : b0;
+          s1[4 * q4 + e] += qcls ? 0.f : b1;
+        }
       }
     }
     float m = sodd;
