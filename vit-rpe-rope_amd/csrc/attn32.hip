@@ -436,6 +436,9 @@ __global__ __launch_bounds__(768, 3) void attn32_fwd_kernel(AttnArgs a) {
   };
   bf16x8 kfo[2];
   odd_rows(32, kfo);
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
   bf16x8 vfo;   // A operand [feature r][k position]: v_odd at position (hh 0, j 0), zero elsewhere
   {
     const bf16 vv = ws[64 + r];
@@ -510,25 +513,32 @@ __global__ __launch_bounds__(768, 3) void attn32_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) m = max3(m, s0[q], s1[q]);
     m = swap32_max(m);
-    float l = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       s0[q] = __builtin_amdgcn_exp2f(s0[q] - m);
       s1[q] = __builtin_amdgcn_exp2f(s1[q] - m);
-      l += s0[q] + s1[q];
     }
     const float podd = __builtin_amdgcn_exp2f(sodd - m);
-    l = swap32_sum(l) + podd;
     bf16x8 pfo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) pfo[j] = (bf16)0.f;
-    pfo[0] = (bf16)podd;                             // (meets zeros of vfo everywhere but at position (0, 0))
-    f32x16 o = z16;
-    mma32(vf[0], pack8<0>(s0), o);
-    mma32(vf[1], pack8<1>(s0), o);
-    mma32(vf[2], pack8<0>(s1), o);
-    mma32(vf[3], pack8<1>(s1), o);
+    pfo[0] = (hh == 0) ? (bf16)podd : (bf16)0.f;     // position (hh 0, j 0) only: the row sum below counts every position
+    const bf16x8 pf0 = pack8<0>(s0), pf1 = pack8<1>(s0), pf2 = pack8<0>(s1), pf3 = pack8<1>(s1);
+    // Row sums on the matrix core: an all-ones A operand against the same P^T fragments gives sum_k P^T[k][query] in every
+    // row -- the 32 in-lane adds and the cross-half exchange leave the vector issue port, which is what this phase runs
+    // out of; the denominator is then the sum of the SAME bf16-rounded probabilities the numerator uses.
+    f32x16 o = z16, lsum = z16;
+    mma32(vf[0], pf0, o);
+    mma32(ones, pf0, lsum);
+    mma32(vf[1], pf1, o);
+    mma32(ones, pf1, lsum);
+    mma32(vf[2], pf2, o);
+    mma32(ones, pf2, lsum);
+    mma32(vf[3], pf3, o);
+    mma32(ones, pf3, lsum);
     mma32(vfo, pfo, o);
+    mma32(ones, pfo, lsum);
+    const float l = lsum[0];
     store_rows(o, __builtin_amdgcn_rcpf(l), i, live);
   }
   stamp(5);
