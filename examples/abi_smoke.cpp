@@ -39,7 +39,7 @@ template <typename T> static T* devz(size_t n) {
 
 int main() {
   const int B = 4, N = 65, D = 192, H = 6, HD = 32, HID = 768, G = 8, M = B * N;
-  if (vitpe_abi_version() != 3) { fprintf(stderr, "ABI version mismatch\n"); return 1; }
+  if (vitpe_abi_version() != 4) { fprintf(stderr, "ABI version mismatch\n"); return 1; }
   if (!vitpe_fused_attention_supported(VITPE_BF16, N, D, HD) || !vitpe_mlp_fwd_supported(VITPE_BF16, D, HID)) {
     fprintf(stderr, "geometry not supported\n");
     return 1;

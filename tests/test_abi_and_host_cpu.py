@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert debug and all("debug" in n or "selftest" in n for n in debug) and not (debug & set(protos))
     assert not any("debug" in n or "selftest" in n for n in protos)
     assert exported == set(protos) | debug, exported ^ (set(protos) | debug)
-    assert _lib.lib().vitpe_abi_version() == 3
+    assert _lib.lib().vitpe_abi_version() == 4
 
 
 def test_pure_host_entry_points():

@@ -1056,4 +1056,4 @@ extern "C" int vitpe_selftest_mma(int dtype, const void* A, const void* Bt, cons
   VITPE_CHECK_LAUNCH();
 }
 
-extern "C" int vitpe_abi_version(void) { return 3; }
+extern "C" int vitpe_abi_version(void) { return 4; }   // 4: + the wide attention forward entry points; block_tail2 keeps gelu'(u) as IEEE half
