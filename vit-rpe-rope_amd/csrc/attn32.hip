@@ -31,6 +31,14 @@
 #include "attn_common.h"
 #include <stdlib.h>
 
+// cache policy of the output stores (raw buffer stores): 0 plain, 2 nt, 16 sc1 = write-through
+#ifndef VITPE_A32_STORE_AUX
+#define VITPE_A32_STORE_AUX 16
+#endif
+#ifndef VITPE_A32_STORE_AUX_XN
+#define VITPE_A32_STORE_AUX_XN 16
+#endif
+
 namespace vitpe {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -348,13 +356,14 @@ __global__ __launch_bounds__(768, 3) void attn32_fwd_kernel(AttnArgs a) {
     if (LNF && a.xn_out != nullptr) {
       const int simg = tid / 384, st = tid % 384, cc = st % 24, r0 = st / 24;
       if (blockIdx.x * 2 + simg < a.B) {
-        bf16* const obase = reinterpret_cast<bf16*>(a.xn_out) + (size_t)blockIdx.x * 2 * N * D;
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<bf16*>(a.xn_out) + (size_t)blockIdx.x * 2 * N * D, 0, 2 * N * D * 2, 0x00020000);
 #pragma unroll
         for (int it = 0; it < 5; ++it) {
           const int row = r0 + 16 * it;
           if (it < 4 || row < N) {
             const Chunk16 c16 = *reinterpret_cast<const Chunk16*>(xs_all + simg * W32::XIMG + row * LDX + cc * 8);
-            __builtin_nontemporal_store(c16, reinterpret_cast<Chunk16*>(obase + (unsigned)(simg * N + row) * (unsigned)D + (unsigned)(cc * 8)));
+            __builtin_amdgcn_raw_buffer_store_b128(c16, xrsrc, (int)(((simg * N + row) * D + cc * 8) * 2), 0, VITPE_A32_STORE_AUX_XN);
           }
         }
       }
@@ -447,7 +456,11 @@ __global__ __launch_bounds__(768, 3) void attn32_fwd_kernel(AttnArgs a) {
     vfo[0] = (hh == 0) ? vv : (bf16)0.f;
   }
 
-  bf16* const outp = reinterpret_cast<bf16*>(a.out) + (size_t)b * N * D + h * 32;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4s;
+  // the workgroup's two images' output rows as one buffer (wave-uniform descriptor, 32-bit byte offsets)
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<bf16*>(a.out) + (size_t)blockIdx.x * 2 * N * D, 0, 2 * N * D * 2, 0x00020000);
+  const unsigned obase = (unsigned)((img * N * D + h * 32) * 2);
   // O^T accumulators -> scaled bf16 rows: lane (query r, hh) holds features 8 m + 4 hh .. + 3 in registers 4 m .. 4 m + 3;
   // one v_permlane32_swap per dword pairs the halves' 8-B pieces into 16 contiguous bytes (features 16 mp + 8 hh .. + 7)
   auto store_rows = [&](const f32x16& o, float inv, int token, bool pred) {
@@ -462,7 +475,8 @@ __global__ __launch_bounds__(768, 3) void attn32_fwd_kernel(AttnArgs a) {
         const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, pa), __builtin_bit_cast(uint32_t, pb), false, false);
         d0[w2] = sw[0]; d1[w2] = sw[1];
       }
-      if (pred) *reinterpret_cast<Chunk16*>(outp + (size_t)token * D + 16 * mp + 8 * hh) = (Chunk16){d0[0], d0[1], d1[0], d1[1]};
+      if (pred) __builtin_amdgcn_raw_buffer_store_b128((u32x4s){d0[0], d0[1], d1[0], d1[1]}, orsrc,
+                                                        (int)(obase + (unsigned)((token * D + 16 * mp + 8 * hh) * 2)), 0, VITPE_A32_STORE_AUX);
     }
   };
 
