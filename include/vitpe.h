@@ -161,37 +161,21 @@ int vitpe_linear_lnbwd(int dtype, const void* dY, const void* Wt, void* dx, cons
 int vitpe_linear_lnbwd2(int dtype, const void* dY, const void* Wt_packed, void* dx, const void* x, const float* mean,
                         const float* rstd, const float* gamma, const void* dres, float* dgamma, float* dbeta, int M,
                         int K, vitpe_stream_t stream);
-/* vitpe_mlp_fwd: the whole MLP branch of a block in one kernel (vit.py:116-118,124 with timm Mlp):
- *   xn = LayerNorm(x) ; u = xn W1^T + b1 ; h = gelu(u) ; out = x + h W2^T + b2
- * x raw rows [M,192] with their LayerNorm statistics mean/rstd (e.g. vitpe_linear's stats output);
- * xn_out (nullable), u_out, h_out [M,HID] are kept for the backward pass; mean_out/rstd_out (both or
- * neither) receive the LayerNorm statistics of the OUTPUT rows.  bf16 (dtype 1), D == 192,
- * HID % 192 == 0 (vitpe_mlp_fwd_supported); anything else returns hipErrorNotSupported -- run
- * vitpe_linear_ln + vitpe_linear instead.                                                        */
-int vitpe_mlp_fwd_supported(int dtype, int D, int HID);
-int vitpe_mlp_fwd(int dtype, const void* x, const float* gamma, const float* beta, const float* mean,
-                  const float* rstd, void* xn_out, const void* W1, const float* b1, const void* W2,
-                  const float* b2, void* u_out, void* h_out, void* out, float* mean_out, float* rstd_out,
-                  float eps, int M, int D, int HID, vitpe_stream_t stream);
-/* vitpe_block_tail_fwd: the attention branch's tail and the MLP branch in one kernel (vit.py:91,122-124):
- *   x_mid = x_in + attn_out Wp^T + bp ;  out = x_mid + fc2(gelu(fc1(LayerNorm2(x_mid))))
- * x_mid [M,192] and its LayerNorm statistics mean2 / rstd2 [M] are outputs (backward needs them); everything
- * else as vitpe_mlp_fwd (eps2: norm2, eps_next: the statistics of `out`).  Same support set.               */
-int vitpe_block_tail_fwd(int dtype, const void* attn_out, const void* x_in, const void* Wp, const float* bp,
-                         const float* gamma, const float* beta, void* x_mid, float* mean2, float* rstd2,
-                         void* xn_out, const void* W1, const float* b1, const void* W2, const float* b2,
-                         void* u_out, void* h_out, void* out, float* mean_out, float* rstd_out, float eps2,
-                         float eps_next, int M, int D, int HID, vitpe_stream_t stream);
-/* vitpe_block_tail2_fwd: the same function as vitpe_block_tail_fwd with each wave carrying one 16-token tile through
- * the whole chain (hidden activation in registers between fc1 and fc2) and the weights read as MFMA fragments from
- * fragment-major packed copies made by vitpe_pack_weight_frags:
+/* vitpe_block_tail2_fwd: the attention branch's tail and the MLP branch of a block in one kernel (vit.py:91,116-118,
+ * 122-124 with timm Mlp):
+ *   x_mid = x_in + attn_out Wp^T + bp ;  xn = LayerNorm2(x_mid) ;  u = xn W1^T + b1 ;  h = gelu(u) ;  out = x_mid + h W2^T + b2
+ * x_mid [M,192] and its LayerNorm statistics mean2 / rstd2 [M] are outputs (backward needs them); xn_out (nullable) is kept
+ * for fc1's weight gradient; mean_out / rstd_out (both or neither) receive the statistics of the OUTPUT rows (the next
+ * block's LayerNorm1; eps2: norm2, eps_next: those).  Each wave carries one 16-token tile through the whole chain (hidden
+ * activation in registers between fc1 and fc2) and reads the weights as MFMA fragments from fragment-major packed copies
+ * made by vitpe_pack_weight_frags:
  *   Wp_packed = pack(attn.proj.weight [192,192], kchunk 192, phi 0)
  *   W1_packed = pack(mlp.fc1.weight  [HID,192], kchunk 192, phi 1)
  *   W2_packed = pack(mlp.fc2.weight  [192,HID], kchunk  32, phi 1)
  * What it keeps of the hidden layer for backward is h_out = gelu(u) (bf16) and gp_out = gelu'(u) [M,HID] as IEEE HALF
  * (2 bytes like bf16, 11 significant bits: vitpe_block_tail2_bwd multiplies every du element by it) -- NOT u: the
  * backward multiplies by the stored derivative; pass both or, for inference, neither.  bf16, D = 192, HID % 64 == 0, 128 <= HID <= 1536 (vitpe_block_tail2_supported); otherwise
- * hipErrorNotSupported.
+ * hipErrorNotSupported -- run vitpe_linear / vitpe_linear_ln instead.
  * vitpe_pack_weight_frags: W fp32 [R,C] (R % 16 == 0, kchunk % 32 == 0, C % kchunk == 0) -> 1-KB fragments
  * (64 lanes x 8 elements) at fragment index ((kc * R/16 + nt) * kchunk/32 + ks); lane 16g + cc, element e holds
  * W[16nt + cc][kchunk*kc + 32ks + k], k = 8g + e (phi 0) or (e < 4 ? 4g + e : 16 + 4g + e - 4) (phi 1).          */
@@ -225,26 +209,6 @@ int vitpe_block_tail2_bwd_pre(int dtype, const void* d_qkv, const void* WqT_pack
                               const void* x_mid, const float* mean2, const float* rstd2, const float* gamma, void* du,
                               void* dx_mid, float* dgamma, float* dbeta, const void* WpT_packed, void* da, int M, int D,
                               int HID, vitpe_stream_t stream);
-/* vitpe_mlp_bwd: backward of that branch w.r.t. its input, same pipeline on the transposed weight shadows:
- *   du = (dy fc2.weight) * gelu'(u)   [M,HID], stored (the fc1 weight gradient reads it)
- *   dx = dy + LayerNorm'(du fc1.weight) ; dgamma / dbeta accumulated (fp32 atomics)
- * W2t = fc2.weight^T [HID,192], W1t = fc1.weight^T [192,HID]; x = the LayerNorm's input rows with statistics
- * mean / rstd and weight gamma.  (The reference gets all of this from autograd.)  Support as vitpe_mlp_fwd. */
-int vitpe_mlp_bwd(int dtype, const void* dy, const void* u, const void* W2t, const void* W1t, const void* x,
-                  const float* mean, const float* rstd, const float* gamma, void* du, void* dx, float* dgamma,
-                  float* dbeta, int M, int D, int HID, vitpe_stream_t stream);
-/* vitpe_block_tail_bwd: vitpe_mlp_bwd plus the data gradient of the attention projection in the same kernel:
- *   da = dx W_proj  [M,192]  (WpT = attn.proj.weight^T), the input of the attention backward.            */
-int vitpe_block_tail_bwd(int dtype, const void* dy, const void* u, const void* W2t, const void* W1t, const void* x,
-                         const float* mean, const float* rstd, const float* gamma, void* du, void* dx,
-                         float* dgamma, float* dbeta, const void* WpT, void* da, int M, int D, int HID,
-                         vitpe_stream_t stream);
-/* vitpe_block_tail_bwd_gp: the same with gp = gelu'(u) [M,HID] in T in place of u (first-generation kernel):
- *   du = (dy fc2.weight) * gp -- no erf evaluation in the backward.                                              */
-int vitpe_block_tail_bwd_gp(int dtype, const void* dy, const void* gp, const void* W2t, const void* W1t, const void* x,
-                         const float* mean, const float* rstd, const float* gamma, void* du, void* dx,
-                         float* dgamma, float* dbeta, const void* WpT, void* da, int M, int D, int HID,
-                         vitpe_stream_t stream);
 /* vitpe_gemm_tn: dW[N,K] += dY[M,N]^T X[M,K] ; dbias[N] += colsum(dY) (NULL to skip).  fp32
  * outputs, accumulated with atomics over `splits` token slices.                             */
 int vitpe_gemm_tn(int dtype, const void* dY, const void* X, float* dW, float* dbias, int M, int N,

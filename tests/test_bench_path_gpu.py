@@ -136,7 +136,7 @@ def _captured_step_against_oracle(tag, extra, B, report_name):
     images, labels = torch.randn(B, 3, 32, 32, generator=g), torch.randint(0, 10, (B,), generator=g)
     ref_logits, ref_loss, ref_grads = O.loss_and_grads(cfg, params, images, labels)
     eng = TrainEngine(model, B, compute_dtype=torch.bfloat16, use_graph=True)
-    assert eng.attn_fused and eng.fuse_ln and eng.fuse_ln_bwd and eng.fuse_mlp and eng.fuse_tail and eng.group_wgrad
+    assert eng.attn_fused and eng.fuse_ln and eng.fuse_ln_bwd and eng.tail2 and eng.group_wgrad
     assert eng.attn_wide == (os.environ.get("VITPE_ATTN_WIDE", "1") == "1")     # the 32x32-tile forward is what the step runs
     grads = graph_step_gradients(eng, images.cuda(), labels.cuda())
     assert eng.graph_fb is not None
@@ -420,10 +420,10 @@ def test_bf16_captured_step_with_layernorm_outputs_recomputed(monkeypatch):
     assert rel_err(eng.logits.cpu(), ref_logits) <= 5e-2 and not bad, bad
 
 
-def test_engine_fragment_packed_shadows_match_the_pack_entry_point_and_first_generation_tail(monkeypatch):
+def test_engine_fragment_packed_shadows_match_the_pack_entry_point_and_the_per_linear_tail(monkeypatch):
     """The second-generation block tail reads attn.proj / fc1 / fc2 from fragment-packed shadows that the batched
     refresh kernel rewrites after every optimizer step: they must equal vitpe_pack_weight_frags of the fp32 masters
-    (before and after a step), and VITPE_TAIL2=0 (first-generation kernels, u saved instead of gelu'(u)) must give the
+    (before and after a step), and VITPE_TAIL2=0 (one panel GEMM per nn.Linear, u saved instead of gelu'(u)) must give the
     same gradients within bf16 noise."""
     from vitpe import kernels as K
     from vitpe.engine import TrainEngine

@@ -42,9 +42,9 @@ def test_standalone_c_caller_matches_python_host(tmp_path):
     bf = torch.bfloat16
     x = _wave(M * D, 0.1, 1.0).view(M, D).to(bf).cuda()
     wqkv = _wave(3 * D * D, 0.7, 0.08).view(3 * D, D).cuda()
-    wp = _wave(D * D, 1.3, 0.07).view(D, D).to(bf).cuda()
-    w1 = _wave(HID * D, 2.1, 0.07).view(HID, D).to(bf).cuda()
-    w2 = _wave(D * HID, 2.9, 0.04).view(D, HID).to(bf).cuda()
+    wp = _wave(D * D, 1.3, 0.07).view(D, D).cuda()
+    w1 = _wave(HID * D, 2.1, 0.07).view(HID, D).cuda()
+    w2 = _wave(D * HID, 2.9, 0.04).view(D, HID).cuda()
     g1, b1 = (1 + _wave(D, 3.3, 0.1)).cuda(), _wave(D, 3.9, 0.1).cuda()
     g2, b2 = (1 + _wave(D, 4.4, 0.1)).cuda(), _wave(D, 5.0, 0.1).cuda()
     bp, bf2_, bf1_ = _wave(D, 5.5, 0.05).cuda(), _wave(D, 6.1, 0.05).cuda(), _wave(HID, 6.6, 0.05).cuda()
@@ -52,8 +52,9 @@ def test_standalone_c_caller_matches_python_host(tmp_path):
     pe = K.PETables("rope-axial", G)
     pe.cos, pe.sin = K.rope_axial_tables(inv, G)
     _, m1, r1 = K.layernorm_fwd(x.view(B, N, D), g1, b1, stats_only=True)
-    att = K.fused_attention_fwd(x.view(B, N, D), K.pack_qkv_weights(wqkv, bf, H), H, pe, ln=(g1, b1, m1, r1))
-    out = K.block_tail_fwd(att.view(M, D), x, wp, bp, g2, b2, w1, bf1_, w2, bf2_)[0].float().cpu().double().flatten()
+    att = K.fused_attention_fwd_wide(x.view(B, N, D), K.pack_qkv_weights_wide(wqkv, bf, H), H, pe, ln=(g1, b1, m1, r1))
+    out = K.block_tail2_fwd(att.view(M, D), x, K.pack_weight_frags(wp, bf, 192, 0), bp, g2, b2, K.pack_weight_frags(w1, bf, 192, 1), bf1_,
+                            K.pack_weight_frags(w2, bf, 32, 1), bf2_)[0].float().cpu().double().flatten()
     w = torch.tensor([(i % 7) + 1 for i in range(out.numel())], dtype=torch.float64)
     assert abs(float(out.sum()) - c_sum) <= 1e-3 * max(1.0, abs(c_sum)) + 0.5     # host-side sinf vs torch.sin: last-ulp input differences
     assert abs(float((out * out * w).sum()) - c_wsq) <= 2e-3 * c_wsq

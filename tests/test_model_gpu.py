@@ -408,7 +408,7 @@ def test_engine_imagenet_geometry_matches_oracle(tag, extra):
     B = 2
     images, labels = O.closed_form_batch(cfg, B)
     eng = TrainEngine(model, B, compute_dtype=torch.float32, use_graph=True)
-    assert not eng.attn_fused and not eng.fuse_mlp
+    assert not eng.attn_fused and not eng.tail2
     eng.images.copy_(images)
     eng.labels.copy_(labels)
     eng.forward_backward()

@@ -16,7 +16,7 @@ import test_bench_path_gpu as TB  # noqa: E402
 
 
 def run(dtype, env, tag="none", seeded=False):
-    for k in ("VITPE_FUSE_LN", "VITPE_FUSE_MLP", "VITPE_FUSE_TAIL", "VITPE_GROUP_WGRAD"):
+    for k in ("VITPE_FUSE_LN", "VITPE_TAIL2", "VITPE_GROUP_WGRAD"):
         os.environ.pop(k, None)
     os.environ.update(env)
     from vitpe.engine import TrainEngine
@@ -40,7 +40,7 @@ def run(dtype, env, tag="none", seeded=False):
 
 for seeded in (False, True):
     for name, dt, env in (("fp32", torch.float32, {}), ("bf16 default", torch.bfloat16, {}),
-                          ("bf16 no fusions", torch.bfloat16, {"VITPE_FUSE_LN": "off", "VITPE_FUSE_MLP": "0", "VITPE_GROUP_WGRAD": "0"})):
+                          ("bf16 no fusions", torch.bfloat16, {"VITPE_FUSE_LN": "off", "VITPE_TAIL2": "0", "VITPE_GROUP_WGRAD": "0"})):
         rep, gn = run(dt, env, seeded=seeded)
         print("random-init" if seeded else "closed-form", name, {k: (round(v, 5) if isinstance(v, float) else v) for k, v in rep.items()}, flush=True)
     print("  |grad|max:", {k: f"{v:.2e}" for k, v in gn.items()})

@@ -1,4 +1,4 @@
-"""Times the block-tail kernels standalone (first generation vs the wave-per-token-tile one):
+"""Times the block-tail kernels standalone (and the panel-GEMM form of the qkv data gradient + LayerNorm1 backward):
    KB_B=512 python tools/kb_tail.py"""
 import os
 import sys
@@ -37,36 +37,27 @@ def main():
     xm, xn, u, h, y = ([e(M, D) for _ in range(ROT)], [e(M, D) for _ in range(ROT)], [e(M, HID) for _ in range(ROT)],
                        [e(M, HID) for _ in range(ROT)], [e(M, D) for _ in range(ROT)])
     m2, r2, mo, ro = (e(M, dt=torch.float32) for _ in range(4))
-    wpb, w1b, w2b = wp.to(T), w1.to(T), w2.to(T)
     wpk, w1k, w2k = K.pack_weight_frags(wp, T, 192, 0), K.pack_weight_frags(w1, T, 192, 1), K.pack_weight_frags(w2, T, 32, 1)
     flop = 2 * M * D * D + 4 * M * D * HID
     byts = (5 * M * D + 2 * M * HID) * 2
 
-    def gen1(i):
-        K.block_tail_fwd(a[i], x[i], wpb, bp, gam, bet, w1b, b1, w2b, b2, x_mid=xm[i], mean2=m2, rstd2=r2, xn_out=xn[i],
-                         u=u[i], h=h[i], out=y[i], stats=(mo, ro))
-
     def gen2(i, save=True, store_xn=True):
         K.block_tail2_fwd(a[i], x[i], wpk, bp, gam, bet, w1k, b1, w2k, b2, x_mid=xm[i], mean2=m2, rstd2=r2,
-                          xn_out=xn[i] if store_xn else None, gp=u[i] if save else None, h=h[i] if save else None, out=y[i],
+                          xn_out=xn[i] if store_xn else None, gp=u[i].view(torch.float16) if save else None, h=h[i] if save else None, out=y[i],
                           stats=(mo, ro), save=save)
 
     # backward
     dy = [r(M, D).to(T) for _ in range(ROT)]
     du, dxm, da = [e(M, HID) for _ in range(ROT)], [e(M, D) for _ in range(ROT)], [e(M, D) for _ in range(ROT)]
     w2t, w1t, wpt = w2.t().contiguous(), w1.t().contiguous(), wp.t().contiguous()
-    w2tb, w1tb, wptb = w2t.to(T), w1t.to(T), wpt.to(T)
     w2tk, w1tk, wptk = K.pack_weight_frags(w2t, T, 192, 0), K.pack_weight_frags(w1t, T, 32, 1), K.pack_weight_frags(wpt, T, 192, 1)
     dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
     K.layernorm_fwd(xm[0], gam, bet, mean=m2, rstd=r2, stats_only=True)
 
-    def bwd1(i):
-        K.block_tail_bwd(dy[i], u[i], w2tb, w1tb, xm[i], m2, r2, gam, dg, db, wptb, du=du[i], out=dxm[i], da=da[i], u_is_gprime=True)
-
     def bwd2(i):
         K.block_tail2_bwd(dy[i], u[i].view(torch.float16), w2tk, w1tk, xm[i], m2, r2, gam, dg, db, wptk, du=du[i], out=dxm[i], da=da[i])
 
-    for name, fn in (("block_tail_fwd  (gen 1)", gen1), ("block_tail2_fwd (gen 2)", gen2),
+    for name, fn in (("block_tail2_fwd", gen2),
                      ("block_tail2_fwd no xn", lambda i: gen2(i, store_xn=False)),
                      ("block_tail2_fwd inference", lambda i: gen2(i, save=False, store_xn=False))):
         us = timeit(fn, rot=ROT)
@@ -75,12 +66,12 @@ def main():
     dq = [r(M, 3 * D).to(T) for _ in range(ROT)]
     wq = r(3 * D, D) * 0.06
     wqt, wqk = wq.t().contiguous().to(T), K.pack_weight_frags(wq.t().contiguous(), T, 192, 0)
-    for name, fn in (("linear_lnbwd  (gen 1) K=576", lambda i: K.linear_lnbwd(dq[i], wqt, xm[i], m2, r2, gam, dy[i], dg, db, out=dxm[i])),
-                     ("linear_lnbwd2 (gen 2) K=576", lambda i: K.linear_lnbwd2(dq[i], wqk, xm[i], m2, r2, gam, dy[i], dg, db, out=dxm[i]))):
+    for name, fn in (("linear_lnbwd  (panel) K=576", lambda i: K.linear_lnbwd(dq[i], wqt, xm[i], m2, r2, gam, dy[i], dg, db, out=dxm[i])),
+                     ("linear_lnbwd2 (tile)  K=576", lambda i: K.linear_lnbwd2(dq[i], wqk, xm[i], m2, r2, gam, dy[i], dg, db, out=dxm[i]))):
         us = timeit(fn, rot=ROT)
         print(f"B={B} {name:30s} {us:8.2f} us = {2 * M * D * 3 * D / us / 1e6:7.1f} TF   {(M * 3 * D + 3 * M * D) * 2 / us / 1e3:7.1f} GB/s", flush=True)
     bb = (4 * M * D + 2 * M * HID) * 2
-    for name, fn in (("block_tail_bwd  (gen 1, gp)", bwd1), ("block_tail2_bwd (gen 2)", bwd2)):
+    for name, fn in (("block_tail2_bwd", bwd2),):
         us = timeit(fn, rot=ROT)
         print(f"B={B} {name:30s} {us:8.2f} us = {flop / us / 1e6:7.1f} TF   {bb / us / 1e3:7.1f} GB/s", flush=True)
 

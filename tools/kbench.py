@@ -86,13 +86,6 @@ def main():
     rec("stats only", timeit(lambda: K.layernorm_fwd(x2, gam, bet, mean=mean_, rstd=rstd_, stats_only=True)), 0, M * D * 2)
     xno = torch.empty_like(x2)
     rec("linear_ln fc1+gelu (+xn out)", timeit(lambda: K.linear_ln(x2, gam, bet, mean_, rstd_, w1, b1, epi=L.EPI_BIAS_GELU, u=u, out=h, xn_out=xno)), fl1)
-    mo_, ro_ = torch.empty(M, device=dev), torch.empty(M, device=dev)
-    rec("mlp_fwd fused (LN+fc1+gelu+fc2+res)", timeit(lambda: K.mlp_fwd(x2, gam, bet, mean_, rstd_, w1, b1, w2, b2, xn_out=xno, u=u, h=h, out=y, stats=(mo_, ro_))), 2 * fl1)
-    xm_, m2_, r2_ = torch.empty_like(x2), torch.empty(M, device=dev), torch.empty(M, device=dev)
-    rec("block_tail_fwd (proj+res+LN2+MLP)", timeit(lambda: K.block_tail_fwd(x2, x2, wp, b2, gam, bet, w1, b1, w2, b2, x_mid=xm_, mean2=m2_, rstd2=r2_, xn_out=xno, u=u, h=h, out=y, stats=(mo_, ro_))), 2 * fl1 + 2 * M * D * D)
-    dgm0, dbt0 = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
-    du_ = torch.empty_like(u)
-    rec("mlp_bwd fused (gelu' + dgrad + LN bwd)", timeit(lambda: K.mlp_bwd(x2, u, w2t, w1t, x2, mean_, rstd_, gam, dgm0, dbt0, du=du_, out=y)), 2 * fl1)
     dgm, dbt2 = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
     rec("linear_lnbwd dgrad fc1 K=768", timeit(lambda: K.linear_lnbwd(h, w1t, x2, mean_, rstd_, gam, x2, dgm, dbt2, out=y)), fl1)
     rec("linear_lnbwd dgrad qkv K=576", timeit(lambda: K.linear_lnbwd(dq2, wqt, x2, mean_, rstd_, gam, x2, dgm, dbt2, out=y)), 2 * M * D * 3 * D)

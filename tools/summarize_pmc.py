@@ -46,12 +46,11 @@ PROBES = {
     "layernorm_fwd": ["ln_fwd_kernel"],
     "layernorm_bwd": ["ln_bwd_kernel"],
 }
-# first-generation block-tail kernels (when the second generation does not run): mangled vs demangled spelling
+# what runs instead when a default is switched off (VITPE_ATTN_WIDE=0, VITPE_LNBWD2=0) or the PRE variant was not profiled
 FALLBACK = {
     "attn_fwd": [["attn_fwd_kernel"]],
     "dgrad_qkv_ln1_bwd": [["gemm_panel_kernel"]],
-    "block_tail_fwd": [["mlp_fwd_kernelIDF16bLi0E"], ["mlp_fwd_kernel<", "0, true"]],
-    "block_tail_bwd": [["block_tail2_bwd_kernel"], ["vitpe::mlp_fwd_kernel<"], ["mlp_fwd_kernelIDF16bLi1E"]],
+    "block_tail_bwd": [["block_tail2_bwd_kernel"]],
 }
 
 

@@ -1308,9 +1308,9 @@ extern "C" int vitpe_pack_qkv_weights(int dtype, const float* wqkv, void* packed
 
 template <typename T, int HD, int D, int MT, int HPP, int KM, int NTOK>
 static int launch_attn3(bool bwd, const AttnArgs& a, hipStream_t s) {
-  static const bool bwd_lds = getenv("VITPE_ATTN_BWD_LDS") != nullptr;   // A/B switch: the LDS-tile backward of round 1
-  if constexpr (sizeof(T) == 2 && D / HD <= 6) {
-    if (bwd && !bwd_lds) {   // register-resident backward: one wave per (image, head), two images per workgroup
+  constexpr bool REG_BWD = sizeof(T) == 2 && D / HD <= 6;   // every bf16 geometry vitpe_fused_attention_supported admits
+  if constexpr (REG_BWD) {
+    if (bwd) {   // register-resident backward: one wave per (image, head), two images per workgroup
       const dim3 grid((a.B + 1) / 2), block(64 * (D / HD) * 2);
       const bool ln = a.ln_gamma != nullptr;
       if constexpr (KM == KM_ROPE) {
@@ -1332,9 +1332,9 @@ static int launch_attn3(bool bwd, const AttnArgs& a, hipStream_t s) {
       VITPE_CHECK_LAUNCH();
     }
   }
-  if (bwd)
-    hipLaunchKernelGGL((attn_bwd_kernel<T, HD, D, MT, HPP, KM, NTOK>), dim3(a.B), dim3(384), 0, s, a);
-  else {  // one wave per (image, head); bf16: two images per workgroup (see attn_fwd_kernel)
+  if (bwd) {   // fp32 (the parity path): the LDS-tile backward; not instantiated for bf16
+    if constexpr (!REG_BWD) hipLaunchKernelGGL((attn_bwd_kernel<T, HD, D, MT, HPP, KM, NTOK>), dim3(a.B), dim3(384), 0, s, a);
+  } else {  // one wave per (image, head); bf16: two images per workgroup (see attn_fwd_kernel)
     constexpr int IPW = (sizeof(T) == 2 && D / HD <= 6) ? 2 : 1;
     const dim3 grid((a.B + IPW - 1) / IPW), block(64 * (D / HD) * IPW);
     if (a.ln_gamma != nullptr) hipLaunchKernelGGL((attn_fwd_kernel<T, HD, D, MT, KM, NTOK, IPW, true>), grid, block, 0, s, a);
@@ -1485,6 +1485,6 @@ extern "C" int vitpe_debug_attn_occupancy(int which) {
   else if (which == 1)
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<bf16, 32, 192, 5, KM_PLAIN, 65, 2, true>, 768, 0);
   else
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_kernel<bf16, 32, 192, 5, 2, KM_ROPE, 65>, 384, 0);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_reg_kernel<32, 192, 5, KM_ROPE, 65, 2, true, false>, 768, 0);
   return e == hipSuccess ? n : -(int)e;
 }

@@ -223,7 +223,7 @@ struct GemmPanelArgs {
 // Two shapes of the same kernel (WR x WC waves, wave tile 48 rows x 192/WC columns):
 //   3 x 4 = 12 waves, tile 144 x 192, 86 KB of LDS: one workgroup per CU;
 //   2 x 3 =  6 waves, tile  96 x 192, 74 KB of LDS: an experiment (two workgroups per CU would let one's
-//   epilogue overlap the other's MFMA phase) that does not pay -- see panel_shape() below.
+//   epilogue overlap the other's MFMA phase) that does not pay -- see launch_gemm_panel_shape below.
 template <typename T, int EPI, bool STATS, bool LNA, int WR, int WC>
 __global__ __launch_bounds__(64 * WR * WC) __attribute__((amdgpu_waves_per_eu(3)))
 void gemm_panel_kernel(GemmPanelArgs a) {
@@ -719,19 +719,9 @@ static int panel_rows_for(int M, int bm, int slots) {
   return rows < 16 ? 16 : rows;
 }
 
-// 1 (default): 3 x 4 waves, 144-row tiles, one workgroup per CU.  0 (VITPE_PANEL_SHAPE=0, A/B measurements
-// only): 2 x 3 waves, 96-row tiles -- meant to run two workgroups per CU, but its 74 KB of LDS is above the
-// 64 KB up to which two workgroups are co-resident on a CU (residency census), so it runs one
-// 6-wave workgroup per CU and is 1.5x SLOWER (fc1+GELU 58 vs 38 us).
-static int panel_shape() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("VITPE_PANEL_SHAPE");
-    v = (e != nullptr && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
-
+// 3 x 4 waves, 144-row tiles, one workgroup per CU.  (A 2 x 3-wave, 96-row shape meant to run two workgroups per CU was
+// measured in round 1: its 74 KB of LDS is above the 64 KB up to which two workgroups are co-resident, so it ran one
+// 6-wave workgroup per CU and was 1.5x slower -- fc1+GELU 58 vs 38 us; no longer instantiated.)
 template <typename T, int WR, int WC>
 static int launch_gemm_panel_shape(int epi, GemmPanelArgs a, hipStream_t s) {
   constexpr int WGS_PER_CU = (WR * WC <= 6) ? 2 : 1;
@@ -769,7 +759,6 @@ static int launch_gemm_panel_shape(int epi, GemmPanelArgs a, hipStream_t s) {
 
 template <typename T>
 static int launch_gemm_panel(int epi, GemmPanelArgs a, hipStream_t s) {
-  if (sizeof(T) == 2 && panel_shape() == 0) return launch_gemm_panel_shape<T, 2, 3>(epi, a, s);
   return launch_gemm_panel_shape<T, 3, 4>(epi, a, s);
 }
 

@@ -304,13 +304,9 @@ bool gemm2d_takes(int dtype, int epi, int M, int N, int K) {
          K % 64 == 0 && K >= 192 && N % 256 == 0 && M >= 2048 && (long long)M * N >= 4LL * 1024 * 1024;
 }
 
-static int g_forced_mt = -1;   // -1: read VITPE_GEMM2D_MT once; 0: heuristic; 4/5/6: forced (vitpe_debug_set_gemm2d_mt)
+static int g_forced_mt = 0;   // 0: heuristic; 4/5/6: forced (vitpe_debug_set_gemm2d_mt, tests and tools/kb_gemm2d.py)
 
 static int gemm2d_pick_mt(int M, int N) {
-  if (g_forced_mt < 0) {
-    const char* e = getenv("VITPE_GEMM2D_MT");
-    g_forced_mt = e ? atoi(e) : 0;
-  }
   const int forced = g_forced_mt;
   if (forced == 4 || forced == 5 || forced == 6) return forced;
   const int cand[3] = {6, 5, 4};

@@ -1,4 +1,4 @@
-// Block tail, second generation ("wave per token tile"): the attention projection + residual + LayerNorm2 + the whole
+// Block tail ("wave per token tile"): the attention projection + residual + LayerNorm2 + the whole
 // MLP branch + residual of a transformer block (reference models/vit.py:91,116-118,122-124; timm Mlp = fc1 -> GELU ->
 // fc2) in one kernel in which the hidden activation NEVER leaves the registers between fc1 and fc2.
 //
@@ -9,8 +9,8 @@
 // rows): an accumulator tile then holds [feature 16nt + 4g + r][token c], i.e. the token on the lane and the FEATURES in
 // the registers -- exactly the layout in which acc_to_frag turns pairs of accumulator tiles into the B operand of the
 // NEXT product, which contracts over those features (common.h).  So LayerNorm2's output feeds fc1 and gelu(fc1) feeds fc2
-// straight from registers: no LDS image of the normalised panel, none of the hidden chunk (the first generation, mlp.hip,
-// parks both: 108 KB, two barriers per 48-row epilogue pass, 63 barriers per workgroup).  The k order acc_to_frag
+// straight from registers: no LDS image of the normalised panel, none of the hidden chunk (the round-1 kernel, retired in
+// round 3, parked both: 108 KB, two barriers per 48-row epilogue pass, 63 barriers per workgroup).  The k order acc_to_frag
 // produces inside a 32-feature chunk (t < 4 -> 4g + t, else 16 + 4g + t - 4) is baked into the packed weight copies ("phi"
 // order), so the weight fragments are plain lane-linear 16-B reads.  Biases are the accumulators' initial values.
 //
@@ -66,7 +66,6 @@ struct Tail2Args {
   float* mean_out;      // statistics of the output rows (next norm1), nullable (both or neither)
   float* rstd_out;
   int M, HID;
-  int nosplit;          // A/B: 1 = the ninth tile of a nine-tile workgroup stays on one wave (VITPE_T2_NOSPLIT)
   float eps2, eps_next;
   unsigned long long* census;   // CENSUS instantiation only (include/vitpe_debug.h)
 };
@@ -285,7 +284,7 @@ __global__ __launch_bounds__(T2F_THREADS) void block_tail2_fwd_kernel(Tail2Args 
   // two compute waves and no loader): both run the proj + LayerNorm2 prologue for the tile, wave 8 then takes the even
   // 64-wide hidden chunks and wave 11 the odd ones (fc1 + GELU of chunk p while slab p is resident, fc2 of chunk p under
   // slab p + 1), and wave 11's partial fc2 sums reach wave 8 through a slab buffer that has gone idle.
-  const bool split = ntile_wg == T2_WAVES && !a.nosplit;
+  const bool split = ntile_wg == T2_WAVES;
   const int half = !split ? -1 : wave == T2_WAVES - 1 ? 0 : wave == T2_WAVES + 2 ? 1 : -1;   // -1: a whole tile
   const bool active = wave < ntile_wg || half == 1;           // wave-uniform
   const int nsig = ntile_wg + (split ? 1 : 0);                // compute waves that count themselves into sDone[]
@@ -1118,8 +1117,8 @@ extern "C" int vitpe_block_tail2_supported(int dtype, int D, int HID) {
   return dtype == 1 && D == T2_D && HID >= 2 * T2_CH && HID % T2_CH == 0 && HID <= T2_MAXHID;
 }
 
-// As vitpe_block_tail_fwd, with the three weights given as vitpe_pack_weight_frags copies: Wp (kchunk 192, natural),
-// W1 (kchunk 192, phi), W2 (kchunk 32, phi); gp_out = gelu'(u) instead of u.  gp_out and h_out: both or neither.
+// The three weights are vitpe_pack_weight_frags copies: Wp (kchunk 192, natural), W1 (kchunk 192, phi), W2 (kchunk 32,
+// phi); gp_out = gelu'(u), not u.  gp_out and h_out: both or neither.
 static int tail2_launch(int dtype, const void* attn_out, const void* x_in, const void* Wp_packed, const float* bp,
                         const float* gamma, const float* beta, void* x_mid, float* mean2, float* rstd2,
                         void* xn_out, const void* W1_packed, const float* b1, const void* W2_packed,
@@ -1141,7 +1140,6 @@ static int tail2_launch(int dtype, const void* attn_out, const void* x_in, const
   if (ntiles <= 256 * 8) grid = (ntiles + 7) / 8;
   else grid = 256 * ((ntiles + 256 * T2_WAVES - 1) / (256 * T2_WAVES));
   a.census = census;
-  { static const bool ns = getenv("VITPE_T2_NOSPLIT") != nullptr; a.nosplit = ns ? 1 : 0; }
   if (census != nullptr) {
     VITPE_REQUIRE(gp_out != nullptr);
     if (exp == 1) hipLaunchKernelGGL((block_tail2_fwd_kernel<true, true, 1>), dim3(grid), dim3(T2F_THREADS), 0, stream, a);

@@ -416,16 +416,13 @@ static int wgrad_group_launch(int dtype, const void* problems, int nprob, unsign
   }
   int R = (2 * ncu) / (total_blocks > 0 ? total_blocks : 1);   // two rounds of workgroups over the CUs
   if (R > 255) R = 255;
-  static const bool table_ok = getenv("VITPE_WGRAD_STREAMK") == nullptr;
   // (many row ranges = many partial-block flushes: with R = 42 for a single layer the atomics cost more than
   // the shared reads save -- measured 91 vs 68 us -- so small problem lists stay on the stream-K path)
-  static const int r_force = getenv("VITPE_WGRAD_RANGES") ? atoi(getenv("VITPE_WGRAD_RANGES")) : 0;
-  if (r_force > 0) R = r_force;
   // (the whole-model list -- 73 blocks -- does not fit the table with 7 row ranges and falls through to stream-K; forcing
   //  6 ranges so that it fits: 298 us against stream-K's 293.5, 5 ranges 319, 4 ranges 374 -- co-location cuts the HBM reads
-  //  by a third but the kernel is bound by CU-side delivery, not by HBM: tools/ab_wgrad.sh.  A 576-slot table that holds 7
+  //  by a third but the kernel is bound by CU-side delivery, not by HBM (round-2 A/B).  A 576-slot table that holds 7
   //  ranges: 352 us -- some XCD then gets more than the 64 workgroups its 32 CUs take in two rounds)
-  if (table_ok && R >= 2 && R <= 8 && R <= min_stages / 4 && max_blocks <= 63 && np <= 31) {
+  if (R >= 2 && R <= 8 && R <= min_stages / 4 && max_blocks <= 63 && np <= 31) {
     // groups = (problem, row range); greedy: next group to the XCD with the fewest workgroups so far
     int len[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool fits = true;
@@ -450,9 +447,8 @@ static int wgrad_group_launch(int dtype, const void* problems, int nprob, unsign
       grid = mx * 8;
     }
   }
-  static const bool windows_ok = !(getenv("VITPE_WGRAD_WINDOWS") && getenv("VITPE_WGRAD_WINDOWS")[0] == '0');
   const int G = ncu & ~7;
-  if (!a.use_table && windows_ok && G >= 8 && total_blocks >= 2 * G && r_force == 0 && table_ok) {
+  if (!a.use_table && G >= 8 && total_blocks >= 2 * G) {
     a.use_table = 2;
     a.total_blocks = total_blocks;
     a.full_rounds = total_blocks / G;
@@ -467,7 +463,7 @@ static int wgrad_group_launch(int dtype, const void* problems, int nprob, unsign
   // lists below two windows (the CIFAR model: 73 blocks): the same placement on (row range, block) pairs when some R fills
   // k rounds of the chip almost exactly -- co-location cuts the fetched bytes by a third (PMC: 1.77 -> 1.20 GB) as the
   // table mode does, without its second, 71 %-full round
-  if (!a.use_table && windows_ok && G >= 8 && total_blocks > 0 && total_blocks < 2 * G && r_force == 0 && table_ok) {
+  if (!a.use_table && G >= 8 && total_blocks > 0 && total_blocks < 2 * G) {
     int bestR = 0, bestk = 0;
     double besteff = 0.0;
     for (int k = 1; k <= 3; ++k) {

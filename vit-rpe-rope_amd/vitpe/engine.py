@@ -51,11 +51,6 @@ class TrainEngine:
             fuse_ln = {"fwd": "fwd", "all": True, "off": False}[os.environ["VITPE_FUSE_LN"]]
         self.fuse_ln = ok and fuse_ln is not False
         self.fuse_ln_bwd = ok and (fuse_ln is True or fuse_ln is None)
-        # whole-MLP-branch forward kernel (bf16, d = 192 only; VITPE_FUSE_MLP=0 falls back to two panel GEMMs)
-        self.fuse_mlp = (self.fuse_ln and compute_dtype == torch.bfloat16
-                         and os.environ.get("VITPE_FUSE_MLP", "1") == "1"
-                         and K.mlp_fwd_supported(compute_dtype, m.embed_dim, m.blocks[0].mlp.fc1.out_features))
-        self.fuse_tail = os.environ.get("VITPE_FUSE_TAIL", "1") == "1"   # proj folded into the MLP kernel
         self.D, self.H, self.Lyr = m.embed_dim, m.num_heads, len(m.blocks)
         self.p = m.patch_size
         self.C = m.patch_embed.weight.shape[1]
@@ -80,15 +75,15 @@ class TrainEngine:
         self.attn_wide = (self.attn_fused and K.fused_attention_wide_supported(self.T, self.N, self.D, self.D // self.H)
                           and os.environ.get("VITPE_ATTN_WIDE", "1") == "1")
         if not self.attn_fused:   # the LayerNorm / MLP fusions hang off the fused attention kernels' geometry
-            self.fuse_ln = self.fuse_ln_bwd = self.fuse_mlp = False
-        # second-generation block-tail forward (a wave per 16-token tile, hidden activation in registers, weights as
-        # fragment-packed shadows, gelu'(u) saved instead of u); VITPE_TAIL2=0 keeps the first generation
-        self.tail2 = (self.fuse_mlp and self.fuse_ln_bwd and self.fuse_tail and os.environ.get("VITPE_TAIL2", "1") == "1"
+            self.fuse_ln = self.fuse_ln_bwd = False
+        # block tail (attn.proj + residual + LayerNorm2 + MLP branch) as one kernel per direction: a wave per 16-token
+        # tile, hidden activation in registers, weights as fragment-packed shadows, gelu'(u) saved (IEEE half) instead
+        # of u.  VITPE_TAIL2=0: the per-Linear panel GEMMs (the comparator tests/test_bench_path_gpu.py runs against)
+        self.tail2 = (self.fuse_ln and self.fuse_ln_bwd and os.environ.get("VITPE_TAIL2", "1") == "1"
                       and K.block_tail2_supported(self.T, self.D, self.hid))
-        self.tail2_bwd = True   # (block_tail2_fwd keeps gelu'(u) as IEEE half: only the second-generation backward reads it)
         # qkv data gradient + LayerNorm1 backward on the same mapping (29.5 vs 31.4 us for the panel kernel; VITPE_LNBWD2=0:
         # the panel kernel on the transposed shadow)
-        self.lnbwd2 = self.tail2 and self.tail2_bwd and os.environ.get("VITPE_LNBWD2", "1") == "1"
+        self.lnbwd2 = self.tail2 and os.environ.get("VITPE_LNBWD2", "1") == "1"
         # ... and run as the PROLOGUE of the block below's tail backward (one kernel per layer boundary; VITPE_FUSE_LNBWD=0: two)
         self.fuse_lnbwd = self.lnbwd2 and os.environ.get("VITPE_FUSE_LNBWD", "1") == "1"
         self._build_flat(lr, weight_decay, betas, eps)
@@ -156,7 +151,7 @@ class TrainEngine:
                 spans.append((w, kind2, o2))
         spans = []
         HDh = self.D // self.H
-        gen2 = self.tail2 and self.tail2_bwd
+        gen2 = self.tail2
         for blk in self.model.blocks:
             qkv, proj, fc1, fc2 = blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight
             self._gemm_weights += [qkv, proj, fc1, fc2]
@@ -253,14 +248,13 @@ class TrainEngine:
         self.labels = torch.zeros(B, dtype=torch.int64, device=dev)
         self.patches = e(B * self.P, self.C * self.p * self.p)
         self.x = [e(B, N, D) for _ in range(self.Lyr + 1)]
-        self.overlap_wgrad = os.environ.get("VITPE_OVERLAP_WGRAD", "0") == "1"
         # weight gradients: one grouped launch per backward part (default) or one GEMM per nn.Linear
-        self.group_wgrad = os.environ.get("VITPE_GROUP_WGRAD", "1") == "1" and not self.overlap_wgrad
+        self.group_wgrad = os.environ.get("VITPE_GROUP_WGRAD", "1") == "1"
         # VITPE_RECOMPUTE_LN=1: LayerNorm outputs are not stored at all -- the attention backward and the weight-gradient
         # kernel re-normalise the raw rows from the saved statistics while staging them (-25.6 MB of stores per layer).
         # Measured neutral-to-slower (the statistics loads cost the weight-gradient kernel, which lives on the vector-
         # memory path, +55..75 us per step; the forward kernels gain ~20 us): off by default, kept for memory-bound boxes.
-        self.recompute_ln = (self.attn_fused and self.fuse_ln and self.fuse_ln_bwd and self.fuse_mlp and self.fuse_tail
+        self.recompute_ln = (self.attn_fused and self.fuse_ln and self.fuse_ln_bwd and self.tail2
                              and self.group_wgrad and os.environ.get("VITPE_RECOMPUTE_LN", "0") == "1")
         xn = (lambda: None) if self.recompute_ln else (lambda: e(B, N, D))
         self.act = []
@@ -282,8 +276,8 @@ class TrainEngine:
         self.head_ws = (f(B, D), f(B, D), f(B))
         self.ws_dyn = f(B, D)
         # Gradient tensors read by the weight-gradient GEMMs get per-layer buffers (dy = d x_out, dmid = d x_mid,
-        # du, dqkv): the weight gradients run on a side stream, and with private buffers the main chain never
-        # overwrites anything they may still be reading (288 GB of HBM: ~0.7 GB extra is free)
+        # du, dqkv): the grouped weight-gradient launch at the end of a backward part reads all of them, so the main
+        # chain must not reuse one across layers (288 GB of HBM: ~0.7 GB extra is free)
         self.dtmp = e(B, N, D)
         self.dx_out = [e(B, N, D) for _ in range(self.Lyr + 1)]   # [l] = gradient w.r.t. x[l]
         self.dx_out[self.Lyr].zero_()   # only its class rows are ever written (head): rows 1.. stay zero
@@ -292,7 +286,6 @@ class TrainEngine:
         self.dqkv_l = [e(B, N, 3 * D) for _ in range(self.Lyr)]
         self.qkv_l = [] if self.attn_fused else [e(B, N, 3 * D) for _ in range(self.Lyr)]
         self.dqkv, self.du = self.dqkv_l[0], self.du_l[0]          # (bench.py times the kernels on these)
-        self.side = torch.cuda.Stream(device=dev)
         self.dataset, self.batch_idx = None, None
         self._wg_groups = {}
         self.dpatch = e(B * self.P, D)
@@ -351,18 +344,12 @@ class TrainEngine:
                                xn_out=a["xn1"])   # (xn1 is None when recompute_ln)
                 nxt = (self.act[l + 1]["m1"], self.act[l + 1]["r1"]) if l + 1 < self.Lyr else None
                 eps_next = mdl.blocks[min(l + 1, self.Lyr - 1)].norm1.eps
-                if self.fuse_mlp and self.fuse_tail:   # proj + residual + LN2 + MLP branch: one kernel per block tail
+                if self.tail2:   # proj + residual + LN2 + MLP branch: one kernel per block tail
                     self._block_tail_fwd(l, blk, a, nxt)
                     continue
                 K.linear(a["a"].view(M, D), self.Sh(blk.attn.proj.weight), blk.attn.proj.bias.data,
                          epi=L.EPI_BIAS_RESID, resid=xin.view(M, D), out=a["xmid"].view(M, D), stats=(a["m2"], a["r2"]),
                          eps=blk.norm2.eps)
-                if self.fuse_mlp:   # LN2 + fc1 + GELU + fc2 + residual (+ next LN1 statistics) in one kernel
-                    K.mlp_fwd(a["xmid"].view(M, D), blk.norm2.weight.data, blk.norm2.bias.data, a["m2"], a["r2"],
-                              self.Sh(blk.mlp.fc1.weight), blk.mlp.fc1.bias.data, self.Sh(blk.mlp.fc2.weight),
-                              blk.mlp.fc2.bias.data, xn_out=a["xn2"].view(M, D), u=a["u"], h=a["h"],
-                              out=self.x[l + 1].view(M, D), stats=nxt, eps=eps_next)
-                    continue
                 K.linear_ln(a["xmid"].view(M, D), blk.norm2.weight.data, blk.norm2.bias.data, a["m2"], a["r2"],
                             self.Sh(blk.mlp.fc1.weight), blk.mlp.fc1.bias.data, epi=L.EPI_BIAS_GELU, u=a["u"], out=a["h"],
                             xn_out=a["xn2"].view(M, D))
@@ -394,21 +381,13 @@ class TrainEngine:
         eps_next = self.model.blocks[min(l + 1, self.Lyr - 1)].norm1.eps
         if save is None:
             save = self._save_hidden
-        if self.tail2:   # wave-per-token-tile kernel on fragment-packed weights; keeps gelu'(u) in a["u"] instead of u
-            K.block_tail2_fwd(a["a"].view(M, D), self.x[l].view(M, D), self.Fr(blk.attn.proj.weight),
-                              blk.attn.proj.bias.data, blk.norm2.weight.data, blk.norm2.bias.data,
-                              self.Fr(blk.mlp.fc1.weight), blk.mlp.fc1.bias.data, self.Fr(blk.mlp.fc2.weight),
-                              blk.mlp.fc2.bias.data, x_mid=a["xmid"].view(M, D), mean2=a["m2"], rstd2=a["r2"],
-                              xn_out=(a["xn2"].view(M, D) if (save and not self.recompute_ln) else None),
-                              gp=(a["u"].view(torch.float16) if save else None), h=(a["h"] if save else None), out=self.x[l + 1].view(M, D),
-                              stats=nxt, eps2=blk.norm2.eps, eps_next=eps_next, save=save)
-            return
-        K.block_tail_fwd(a["a"].view(M, D), self.x[l].view(M, D), self.Sh(blk.attn.proj.weight),
-                         blk.attn.proj.bias.data, blk.norm2.weight.data, blk.norm2.bias.data,
-                         self.Sh(blk.mlp.fc1.weight), blk.mlp.fc1.bias.data, self.Sh(blk.mlp.fc2.weight),
-                         blk.mlp.fc2.bias.data, x_mid=a["xmid"].view(M, D), mean2=a["m2"], rstd2=a["r2"],
-                         xn_out=(None if self.recompute_ln else a["xn2"].view(M, D)), u=a["u"], h=a["h"],
-                         out=self.x[l + 1].view(M, D), stats=nxt, eps2=blk.norm2.eps, eps_next=eps_next)
+        K.block_tail2_fwd(a["a"].view(M, D), self.x[l].view(M, D), self.Fr(blk.attn.proj.weight),
+                          blk.attn.proj.bias.data, blk.norm2.weight.data, blk.norm2.bias.data,
+                          self.Fr(blk.mlp.fc1.weight), blk.mlp.fc1.bias.data, self.Fr(blk.mlp.fc2.weight),
+                          blk.mlp.fc2.bias.data, x_mid=a["xmid"].view(M, D), mean2=a["m2"], rstd2=a["r2"],
+                          xn_out=(a["xn2"].view(M, D) if (save and not self.recompute_ln) else None),
+                          gp=(a["u"].view(torch.float16) if save else None), h=(a["h"] if save else None), out=self.x[l + 1].view(M, D),
+                          stats=nxt, eps2=blk.norm2.eps, eps_next=eps_next, save=save)
 
     def _block_tail_bwd(self, l, blk, a, pre=False):
         """pre: the qkv data gradient + LayerNorm1 backward of block l + 1 run first in the same kernel and produce
@@ -423,16 +402,10 @@ class TrainEngine:
                                   G(blk.norm2.weight), G(blk.norm2.bias), self.Frt(blk.attn.proj.weight), du=self.du_l[l],
                                   out=self.dx_mid[l].view(M, D), da=self.dtmp.view(M, D))
             return
-        if self.tail2 and self.tail2_bwd:
-            K.block_tail2_bwd(self.dx_out[l + 1].view(M, D), a["u"].view(torch.float16), self.Frt(blk.mlp.fc2.weight), self.Frt(blk.mlp.fc1.weight),
-                              a["xmid"].view(M, D), a["m2"], a["r2"], blk.norm2.weight.data, G(blk.norm2.weight),
-                              G(blk.norm2.bias), self.Frt(blk.attn.proj.weight), du=self.du_l[l],
-                              out=self.dx_mid[l].view(M, D), da=self.dtmp.view(M, D))
-            return
-        K.block_tail_bwd(self.dx_out[l + 1].view(M, D), a["u"], self.St(blk.mlp.fc2.weight), self.St(blk.mlp.fc1.weight),
-                         a["xmid"].view(M, D), a["m2"], a["r2"], blk.norm2.weight.data, G(blk.norm2.weight),
-                         G(blk.norm2.bias), self.St(blk.attn.proj.weight), du=self.du_l[l], out=self.dx_mid[l].view(M, D),
-                         da=self.dtmp.view(M, D), u_is_gprime=self.tail2)
+        K.block_tail2_bwd(self.dx_out[l + 1].view(M, D), a["u"].view(torch.float16), self.Frt(blk.mlp.fc2.weight),
+                          self.Frt(blk.mlp.fc1.weight), a["xmid"].view(M, D), a["m2"], a["r2"], blk.norm2.weight.data,
+                          G(blk.norm2.weight), G(blk.norm2.bias), self.Frt(blk.attn.proj.weight), du=self.du_l[l],
+                          out=self.dx_mid[l].view(M, D), da=self.dtmp.view(M, D))
 
     def _tail_bytes(self, fwd: bool) -> int:
         """Algorithmic HBM bytes of one block-tail launch (what the kernel must read and write once)."""
@@ -493,23 +466,15 @@ class TrainEngine:
         for grp in self._wg_groups[part]:
             grp.launch()
 
-    def _wgrad(self, after_event, fn):
-        """Run a weight-gradient GEMM on the side stream once `after_event` (its producer) has completed."""
-        if self.group_wgrad:
-            return
-        if not self.overlap_wgrad:
-            fn()
-            return
-        self.side.wait_event(after_event)
-        with torch.cuda.stream(self.side):
+    def _wgrad(self, fn):
+        """One weight-gradient GEMM per nn.Linear (VITPE_GROUP_WGRAD=0); the default leaves them to _wgrad_group."""
+        if not self.group_wgrad:
             fn()
 
     def _backward(self, part="all"):
         """part: "all" | "upper" (head + layers L-1..split) | "lower" (layers split-1..0 + patch embed)."""
         mdl, B, N, D, M = self.model, self.B, self.N, self.D, self.M
         G = self.Gr
-        main = torch.cuda.current_stream()
-        ev = lambda: (lambda e: (e.record(main), e)[1])(torch.cuda.Event())  # noqa: E731
         hi, lo = self.Lyr - 1, 0
         if part == "upper":
             lo = self.split_layer
@@ -524,24 +489,18 @@ class TrainEngine:
             blk, a = mdl.blocks[l], self.act[l]
             dy3, dmid3, du, dqkv = self.dx_out[l + 1], self.dx_mid[l], self.du_l[l], self.dqkv_l[l]
             dy = dy3.view(M, D)
-            e_dy = ev()
             # ---- MLP branch: x_out = xmid + fc2(gelu(fc1(LN2(xmid))))
-            self._wgrad(e_dy, lambda: K.gemm_tn(dy, a["h"], G(blk.mlp.fc2.weight), G(blk.mlp.fc2.bias)))
+            self._wgrad(lambda: K.gemm_tn(dy, a["h"], G(blk.mlp.fc2.weight), G(blk.mlp.fc2.bias)))
             fc1_wgrad = lambda: K.gemm_tn(du, a["xn2"].view(M, D), G(blk.mlp.fc1.weight), G(blk.mlp.fc1.bias))  # noqa: E731
             tail_done = False
-            if self.fuse_mlp and self.fuse_ln_bwd and self.fuse_tail:   # ... + the projection's data gradient
+            if self.tail2:   # gelu' + both data gradients + LayerNorm2 backward + residual + the projection's data gradient
                 self._block_tail_bwd(l, blk, a, pre=(self.fuse_lnbwd and self.group_wgrad and l < hi))   # (+ block l + 1's qkv data gradient;
                 # per-GEMM weight gradients would read dy before the fused kernel has written it)
-                self._wgrad(ev(), fc1_wgrad)
+                self._wgrad(fc1_wgrad)
                 tail_done = True
-            elif self.fuse_mlp and self.fuse_ln_bwd:   # gelu' + both data gradients + LayerNorm2 backward + residual
-                K.mlp_bwd(dy, a["u"], self.St(blk.mlp.fc2.weight), self.St(blk.mlp.fc1.weight), a["xmid"].view(M, D),
-                          a["m2"], a["r2"], blk.norm2.weight.data, G(blk.norm2.weight), G(blk.norm2.bias), du=du,
-                          out=dmid3.view(M, D))
-                self._wgrad(ev(), fc1_wgrad)
             else:
                 K.linear(dy, self.St(blk.mlp.fc2.weight), None, epi=L.EPI_GELU_BWD, u=a["u"], out=du)
-                self._wgrad(ev(), fc1_wgrad)
+                self._wgrad(fc1_wgrad)
                 if self.fuse_ln_bwd:   # data gradient of fc1 + LayerNorm2 backward + residual add in one kernel
                     K.linear_lnbwd(du, self.St(blk.mlp.fc1.weight), a["xmid"].view(M, D), a["m2"], a["r2"],
                                    blk.norm2.weight.data, dy, G(blk.norm2.weight), G(blk.norm2.bias),
@@ -552,8 +511,7 @@ class TrainEngine:
                                     G(blk.norm2.bias), dres=dy3, out=dmid3, workspace=self.ln_ws)
             # ---- attention branch: xmid = x_in + proj(attn(LN1(x_in)))
             dm = dmid3.view(M, D)
-            e_dm = ev()
-            self._wgrad(e_dm, lambda: K.gemm_tn(dm, a["a"].view(M, D), G(blk.attn.proj.weight), G(blk.attn.proj.bias)))
+            self._wgrad(lambda: K.gemm_tn(dm, a["a"].view(M, D), G(blk.attn.proj.weight), G(blk.attn.proj.bias)))
             if not tail_done:
                 K.linear(dm, self.St(blk.attn.proj.weight), None, out=self.dtmp.view(M, D))
             if self.attn_fused and self.recompute_ln:
@@ -564,8 +522,7 @@ class TrainEngine:
                                       out=dqkv, **self.pe_grads)
             else:
                 K.attention_core_bwd(self.qkv_l[l], self.dtmp, self.H, self.pe, out=dqkv, **self.pe_grads)
-            e_dq = ev()
-            self._wgrad(e_dq, lambda: K.gemm_tn(dqkv.view(M, 3 * D), a["xn1"].view(M, D), G(blk.attn.qkv.weight), None))
+            self._wgrad(lambda: K.gemm_tn(dqkv.view(M, 3 * D), a["xn1"].view(M, D), G(blk.attn.qkv.weight), None))
             if self.fuse_lnbwd and self.group_wgrad and l > lo:
                 pass   # runs as the prologue of block l - 1's tail backward (next iteration)
             elif self.fuse_ln_bwd and self.lnbwd2:   # ... on the wave-per-tile mapping, packed qkv.weight^T
@@ -589,8 +546,6 @@ class TrainEngine:
                 K.gemm_tn(self.dpatch, self.patches, G(mdl.patch_embed.weight).view(D, -1), G(mdl.patch_embed.bias))
         if self.group_wgrad:
             self._wgrad_group(part)
-        if self.overlap_wgrad:
-            main.wait_stream(self.side)   # join: every gradient is complete before the all-reduce / optimizer
 
     def _optimizer(self):
         K.adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.hp, shadow_bf16=self.flat_s, ticked=getattr(self, "_ticked", False),
@@ -853,7 +808,7 @@ class TrainEngine:
                                fns=[(lambda l=l: K.attention_core_bwd(self.qkv_l[l], self.dx_mid[l], Hh, self.pe,
                                                                       out=self.dqkv_l[l], **self.pe_grads))
                                     for l in range(self.Lyr)], flop=2 * attn_core_flop, bytes=(3 + 1 + 3) * M * D * es))
-        if self.fuse_mlp and self.fuse_ln_bwd and self.fuse_tail and self.group_wgrad:
+        if self.tail2 and self.group_wgrad:
             def tail_f(l):
                 blk, a = mdl.blocks[l], self.act[l]
                 nxt = (self.act[l + 1]["m1"], self.act[l + 1]["r1"]) if l + 1 < self.Lyr else None
@@ -863,16 +818,16 @@ class TrainEngine:
                 return lambda: self._block_tail_bwd(l, blk, a)
             tail_flop = 2 * M * D * D + 2 * 2 * M * D * hid
             probes.append(dict(name="block_tail_fwd",
-                               kernel=("block_tail2_fwd_kernel" if self.tail2 else "mlp_fwd_kernel") +
+                               kernel="block_tail2_fwd_kernel" +
                                " (proj+residual+LN2+fc1+GELU+fc2+residual+stats)",
                                fns=[tail_f(l) for l in range(self.Lyr)], flop=tail_flop,
                                bytes=self._tail_bytes(fwd=True)))
             probes.append(dict(name="block_tail_bwd",
-                               kernel=("block_tail2_bwd_kernel" if self.tail2 and self.tail2_bwd else "mlp_fwd_kernel<BWD>") +
+                               kernel="block_tail2_bwd_kernel" +
                                " (gelu'+dgrad fc2/fc1+LN2 bwd+residual+dgrad proj)",
                                fns=[tail_b(l) for l in range(self.Lyr)], flop=tail_flop,
                                bytes=self._tail_bytes(fwd=False)))
-            if self.tail2 and self.tail2_bwd and self.fuse_lnbwd and self.Lyr > 1:
+            if self.fuse_lnbwd and self.Lyr > 1:
                 def tail_bp(l):
                     blk, a = mdl.blocks[l], self.act[l]
                     return lambda: self._block_tail_bwd(l, blk, a, pre=True)

@@ -7,7 +7,6 @@ in Python; there is no fallback path.
 from __future__ import annotations
 
 import ctypes
-import os
 from typing import Optional, Tuple
 
 import torch
@@ -15,7 +14,7 @@ import torch
 from . import _lib as L
 from ._lib import check, dtype_code, lib, ptr, require_device, stream_ptr
 
-SPLITS_TARGET_WGS = int(os.environ.get("VITPE_WGRAD_WGS", "512"))  # workgroups a weight-gradient launch should expose
+SPLITS_TARGET_WGS = 512  # workgroups a weight-gradient launch should expose
 
 
 def _f32(t, name):
@@ -127,56 +126,6 @@ def gemm_tn(dy, x, dw, dbias=None, splits=None):
                               stream_ptr()), "vitpe_gemm_tn")
 
 
-def mlp_fwd_supported(dtype, D, HID):
-    return bool(lib().vitpe_mlp_fwd_supported(dtype_code(dtype), D, HID))
-
-
-def mlp_fwd(x, gamma, beta, mean, rstd, w1, b1, w2, b2, xn_out=None, u=None, h=None, out=None, stats=None, eps=1e-5):
-    """Fused MLP branch: out = x + fc2(gelu(fc1(LayerNorm(x)))) on raw rows x [M,192] with their LayerNorm
-    statistics; returns (out, u, h).  stats=(mean_out, rstd_out) receives the statistics of the output rows."""
-    require_device(x, gamma, beta, mean, rstd, w1, b1, w2, b2, xn_out, u, h, out)
-    M, D = x.shape
-    HID = w1.shape[0]
-    assert w1.shape == (HID, D) and w2.shape == (D, HID) and x.dtype == w1.dtype == w2.dtype
-    _f32(gamma, "gamma"), _f32(beta, "beta"), _f32(b1, "b1"), _f32(b2, "b2")
-    u = u if u is not None else torch.empty((M, HID), dtype=x.dtype, device=x.device)
-    h = h if h is not None else torch.empty((M, HID), dtype=x.dtype, device=x.device)
-    out = out if out is not None else torch.empty_like(x)
-    mo, ro = stats if stats is not None else (None, None)
-    require_device(mo, ro)
-    check(lib().vitpe_mlp_fwd(dtype_code(x.dtype), ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(xn_out),
-                              ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(u), ptr(h), ptr(out), ptr(mo), ptr(ro), float(eps),
-                              M, D, HID, stream_ptr()), "vitpe_mlp_fwd")
-    return out, u, h
-
-
-def block_tail_fwd(attn_out, x_in, wp, bp, gamma, beta, w1, b1, w2, b2, x_mid=None, mean2=None, rstd2=None, xn_out=None,
-                   u=None, h=None, out=None, stats=None, eps2=1e-5, eps_next=1e-5):
-    """x_mid = x_in + proj(attn_out); out = x_mid + mlp(LayerNorm2(x_mid)) in one kernel.
-    Returns (out, x_mid, mean2, rstd2, u, h)."""
-    require_device(attn_out, x_in, wp, bp, gamma, beta, w1, b1, w2, b2, x_mid, mean2, rstd2, xn_out, u, h, out)
-    M, D = attn_out.shape
-    HID = w1.shape[0]
-    assert x_in.shape == (M, D) and wp.shape == (D, D) and w1.shape == (HID, D) and w2.shape == (D, HID)
-    assert attn_out.dtype == x_in.dtype == wp.dtype == w1.dtype == w2.dtype
-    for t_, n_ in ((bp, "bp"), (gamma, "gamma"), (beta, "beta"), (b1, "b1"), (b2, "b2")):
-        _f32(t_, n_)
-    dt, dev = attn_out.dtype, attn_out.device
-    x_mid = x_mid if x_mid is not None else torch.empty((M, D), dtype=dt, device=dev)
-    mean2 = mean2 if mean2 is not None else torch.empty(M, dtype=torch.float32, device=dev)
-    rstd2 = rstd2 if rstd2 is not None else torch.empty(M, dtype=torch.float32, device=dev)
-    u = u if u is not None else torch.empty((M, HID), dtype=dt, device=dev)
-    h = h if h is not None else torch.empty((M, HID), dtype=dt, device=dev)
-    out = out if out is not None else torch.empty((M, D), dtype=dt, device=dev)
-    mo, ro = stats if stats is not None else (None, None)
-    require_device(mo, ro)
-    check(lib().vitpe_block_tail_fwd(dtype_code(dt), ptr(attn_out), ptr(x_in), ptr(wp), ptr(bp), ptr(gamma), ptr(beta),
-                                     ptr(x_mid), ptr(mean2), ptr(rstd2), ptr(xn_out), ptr(w1), ptr(b1), ptr(w2), ptr(b2),
-                                     ptr(u), ptr(h), ptr(out), ptr(mo), ptr(ro), float(eps2), float(eps_next), M, D, HID,
-                                     stream_ptr()), "vitpe_block_tail_fwd")
-    return out, x_mid, mean2, rstd2, u, h
-
-
 def pack_weight_frags(w, dtype, kchunk, phi, out=None):
     """Fragment-major packed copy of the fp32 weight w [R, C] (include/vitpe.h: vitpe_pack_weight_frags)."""
     require_device(w, out)
@@ -195,7 +144,8 @@ def block_tail2_supported(dtype, D, HID) -> bool:
 
 def block_tail2_fwd(attn_out, x_in, wp_pk, bp, gamma, beta, w1_pk, b1, w2_pk, b2, x_mid=None, mean2=None, rstd2=None,
                     xn_out=None, gp=None, h=None, out=None, stats=None, eps2=1e-5, eps_next=1e-5, save=True):
-    """block_tail_fwd on packed weights (pack_weight_frags: wp kchunk 192 natural, w1 kchunk 192 phi, w2 kchunk 32
+    """The block tail -- x_mid = x_in + attn_out Wp^T + bp; out = x_mid + fc2(gelu(fc1(LN2(x_mid)))) -- in one kernel on
+    packed weights (pack_weight_frags: wp kchunk 192 natural, w1 kchunk 192 phi, w2 kchunk 32
     phi).  What it keeps of the hidden layer for backward is gp = gelu'(u) and h = gelu(u) (save=True), or nothing.
     Returns (out, x_mid, mean2, rstd2, gp, h)."""
     require_device(attn_out, x_in, wp_pk, bp, gamma, beta, w1_pk, b1, w2_pk, b2, x_mid, mean2, rstd2, xn_out, gp, h, out)
@@ -223,40 +173,6 @@ def block_tail2_fwd(attn_out, x_in, wp_pk, bp, gamma, beta, w1_pk, b1, w2_pk, b2
                                       ptr(b2), ptr(gp), ptr(h), ptr(out), ptr(mo), ptr(ro), float(eps2), float(eps_next),
                                       M, D, HID, stream_ptr()), "vitpe_block_tail2_fwd")
     return out, x_mid, mean2, rstd2, gp, h
-
-
-def mlp_bwd(dy, u, w2t, w1t, x, mean, rstd, gamma, dgamma, dbeta, du=None, out=None):
-    """Backward of mlp_fwd w.r.t. x: -> (dx, du); dgamma/dbeta accumulated.  w2t = fc2.weight^T [HID,192],
-    w1t = fc1.weight^T [192,HID]."""
-    require_device(dy, u, w2t, w1t, x, mean, rstd, gamma, dgamma, dbeta, du, out)
-    M, D = dy.shape
-    HID = u.shape[1]
-    assert w2t.shape == (HID, D) and w1t.shape == (D, HID) and dy.dtype == u.dtype == w2t.dtype == w1t.dtype == x.dtype
-    _f32(gamma, "gamma"), _f32(dgamma, "dgamma"), _f32(dbeta, "dbeta")
-    du = du if du is not None else torch.empty_like(u)
-    out = out if out is not None else torch.empty_like(dy)
-    check(lib().vitpe_mlp_bwd(dtype_code(dy.dtype), ptr(dy), ptr(u), ptr(w2t), ptr(w1t), ptr(x), ptr(mean), ptr(rstd),
-                              ptr(gamma), ptr(du), ptr(out), ptr(dgamma), ptr(dbeta), M, D, HID, stream_ptr()),
-          "vitpe_mlp_bwd")
-    return out, du
-
-
-def block_tail_bwd(dy, u, w2t, w1t, x, mean, rstd, gamma, dgamma, dbeta, wpt, du=None, out=None, da=None, u_is_gprime=False):
-    """mlp_bwd + da = dx @ proj.weight (wpt = proj.weight^T) in one kernel -> (dx, du, da).  u_is_gprime: `u` holds
-    gelu'(u) as saved by block_tail2_fwd (vitpe_block_tail_bwd_gp) instead of the pre-activation."""
-    require_device(dy, u, w2t, w1t, x, mean, rstd, gamma, dgamma, dbeta, wpt, du, out, da)
-    M, D = dy.shape
-    HID = u.shape[1]
-    assert w2t.shape == (HID, D) and w1t.shape == (D, HID) and wpt.shape == (D, D)
-    assert dy.dtype == u.dtype == w2t.dtype == w1t.dtype == x.dtype == wpt.dtype
-    _f32(gamma, "gamma"), _f32(dgamma, "dgamma"), _f32(dbeta, "dbeta")
-    du = du if du is not None else torch.empty_like(u)
-    out = out if out is not None else torch.empty_like(dy)
-    da = da if da is not None else torch.empty_like(dy)
-    fn = lib().vitpe_block_tail_bwd_gp if u_is_gprime else lib().vitpe_block_tail_bwd
-    check(fn(dtype_code(dy.dtype), ptr(dy), ptr(u), ptr(w2t), ptr(w1t), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(du),
-             ptr(out), ptr(dgamma), ptr(dbeta), ptr(wpt), ptr(da), M, D, HID, stream_ptr()), "vitpe_block_tail_bwd")
-    return out, du, da
 
 
 def block_tail2_bwd(dy, gp, w2t_pk, w1t_pk, x_mid, mean2, rstd2, gamma, dgamma, dbeta, wpt_pk, du=None, out=None, da=None):
