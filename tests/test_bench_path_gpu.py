@@ -12,6 +12,8 @@ Tolerances (bf16 activations carry 8 significant bits through 6 resp. 12 layers;
   every grad max-norm rel <= 5e-2  AND  cosine >= 0.999
   dWqkv / d table / d freqs / d coeff additionally per ROW: ||row_a - row_b||_2 <= 0.08 ||row_b||_2 + 0.01 max_row||row_b||_2
   (the floor only admits rows whose whole norm is below 1 % of the largest row's -- they are dominated by rounding).
+  one tensor, one case: the SHARED polynomial coefficients at B = 512 -- max-norm error <= 5e-2 of the size of the summands
+  before they cancel (_summand_scale), instead of the cancelled sum.
 """
 import json
 import os
@@ -81,17 +83,28 @@ def graph_step_gradients(eng, images, labels):
     return out
 
 
-def compare_all(tagname, model, grads, ref_grads, report):
+def compare_all(tagname, model, grads, ref_grads, report, summand_scale=None):
     """Fills report[tagname] with the worst figures and returns the list of violated checks (asserted by the caller
-    after the report has been written, so a failing run still leaves every number behind)."""
+    after the report has been written, so a failing run still leaves every number behind).
+    summand_scale: {name: s} -- for these tensors the max-norm error is taken relative to max(|ref|, s), s = the size of
+    the summands BEFORE they cancel (see _summand_scale), and the direction checks, which are relative to the cancelled
+    sum, are skipped."""
     worst = {"rel": 0.0, "cos": 1.0, "row": 0.0}
     bad = []
+    summand_scale = summand_scale or {}
     for n, p in model.named_parameters():
         mine, ref = grads[n].numpy(), ref_grads[n].numpy()
         if n == "pos_embed.pos_embed":                 # 5000 rows, only the first P receive gradient
             if mine.shape[1] > ref.shape[1] and float(np.abs(mine[:, ref.shape[1]:]).max()) != 0.0:
                 bad.append((n, "unused rows", 0))
             mine = mine[:, :ref.shape[1]]
+        if n in summand_scale:
+            r = float(np.abs(np.asarray(mine, np.float64) - ref).max() / max(float(np.abs(ref).max()), summand_scale[n]))
+            worst["rel_vs_summands:" + n] = r
+            worst["rel_vs_sum:" + n] = rel_err(mine, ref)
+            if r > 5e-2:
+                bad.append((n, "rel_vs_summands", r))
+            continue
         if float(np.abs(ref).max()) == 0.0:
             if float(np.abs(mine).max()) != 0.0:
                 bad.append((n, "nonzero", float(np.abs(mine).max())))
@@ -101,12 +114,7 @@ def compare_all(tagname, model, grads, ref_grads, report):
             worst["rel"], worst["rel_at"] = r, n
         if c < worst["cos"]:
             worst["cos"], worst["cos_at"] = c, n
-        # One tensor gets a wider max-norm gate, and only at B = 512: the SHARED polynomial coefficients, a [degree + 1] vector
-        # summed over layers, heads, images and token pairs whose terms largely cancel -- the more so the more images are
-        # averaged.  Measured: 0.013 at B = 16 (0.088 before gelu'(u) was kept as IEEE half), 0.058 at B = 512, direction
-        # intact (cosine 0.9998); the per-head variant of the same tensor 0.002, the fp32 engine 2e-5: what is left is the
-        # 8-bit rounding of q, k, v themselves, not a kernel's.
-        if r > (8e-2 if (tagname == "polynomial@B512" and n == "pos_embed.coefficients") else 5e-2):
+        if r > 5e-2:
             bad.append((n, "rel", r))
         if c < 0.999:
             bad.append((n, "cos", c))
@@ -126,6 +134,22 @@ def _dump(report, name):
         f.write(json.dumps(report) + "\n")
 
 
+def _summand_scale(cfg, params, images, labels, ref_grads, name, chunk=64):
+    """The SHARED polynomial coefficients' gradient is a [degree + 1] vector summed over layers, heads, images and token
+    pairs, and the more images are averaged the more of it cancels: at B = 512 its max-norm ranges from 0.003 to 0.12 with
+    the seed of the batch while the bf16 step's ABSOLUTE error stays at 1e-4 .. 1e-3 (both attention forward kernels, three
+    seeds: DESIGN.md round-3 log), so an error relative to the sum measures the luck of the batch, not a kernel.  The gate
+    for this one tensor is therefore relative to the summands: the oracle's gradient of every 64-image chunk of the batch
+    on its own (their mean IS the batch gradient: checked), scale = the mean of their max-norms."""
+    B = images.shape[0]
+    assert B % chunk == 0
+    parts = [O.loss_and_grads(cfg, params, images[i:i + chunk], labels[i:i + chunk])[2][name].numpy().astype(np.float64)
+             for i in range(0, B, chunk)]
+    scale = float(np.mean([np.abs(g).max() for g in parts]))
+    assert np.abs(np.mean(parts, axis=0) - ref_grads[name].numpy()).max() <= 1e-3 * scale
+    return {name: scale}
+
+
 def _captured_step_against_oracle(tag, extra, B, report_name):
     from vitpe.engine import TrainEngine
     cfg, model = build(tag, extra, {}, seeded=True)
@@ -142,7 +166,8 @@ def _captured_step_against_oracle(tag, extra, B, report_name):
     assert eng.graph_fb is not None
     report = {}
     key = tag if B == 16 else f"{tag}@B{B}"
-    bad = compare_all(key, model, grads, ref_grads, report)
+    scale = _summand_scale(cfg, params, images, labels, ref_grads, "pos_embed.coefficients") if (tag == "polynomial" and B >= 128) else None
+    bad = compare_all(key, model, grads, ref_grads, report, summand_scale=scale)
     report[key]["logits"] = rel_err(eng.logits.cpu(), ref_logits)
     _dump(report, report_name)
     assert rel_err(eng.logits.cpu(), ref_logits) <= 5e-2
