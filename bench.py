@@ -129,8 +129,8 @@ def kernel_records(eng, args, peak_tflops):
             gbs = pr["bytes"] / (ms * 1e-3) / 1e9
             rec.update(achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
                        tflops=round(tf, 2))
-        key = f'{pr["name"]}|B{args.batch}|{args.pos_encoding}|{args.dtype}'
-        ent = (pmc or {}).get("entries", {}).get(key) if args.config == "cifar" else None
+        key = f'{pr["name"]}|B{args.batch}|{args.pos_encoding}|{args.dtype}' + ("" if args.config == "cifar" else "|" + args.config)
+        ent = (pmc or {}).get("entries", {}).get(key)
         rec.update(launch_ms=round(ms, 5), algorithmic_flop_per_launch=pr["flop"], algorithmic_bytes_per_launch=pr["bytes"],
                    ai_flop_per_byte=round(ai, 1), roof_tflops=round(roof_tf, 1),
                    traffic=(ent["hbm_bytes_per_launch"] if ent else None),
@@ -337,7 +337,7 @@ def main(argv=None):
             line["roofline"].update({k: v for k, v in head.items() if k not in line["roofline"] and k != "name"})
             line["other_kernels"] = [r for r in recs if r["name"] != "attn_fwd"]
         if world == 1 and not args.no_cpu_baseline and not dry:
-            line["cpu_baseline"] = (cpu_baseline(args.pos_encoding, steps=6, warmup=1, bs=8, cfg_kw=geom, img=img) if imnet
+            line["cpu_baseline"] = (cpu_baseline(args.pos_encoding, steps=20, warmup=1, bs=8, cfg_kw=geom, img=img) if imnet
                                     else cpu_baseline(args.pos_encoding))
         print(json.dumps(line), flush=True)
     if world > 1:

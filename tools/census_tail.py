@@ -23,13 +23,17 @@ nwg = (nt + 7) // 8 if nt <= 2048 else 256 * ((nt + 2303) // 2304)
 cen = torch.zeros(nwg * 9 * 16, dtype=torch.int64, device=dev)
 p = lambda t: t.data_ptr()  # noqa: E731
 for _ in range(3):
-    _lib.check(h.vitpe_debug_tail2_census(p(a), p(x), p(wpk), p(bp), p(gam), p(bet), p(xm), p(m2), p(r2), p(xn), p(w1k), p(b1),
+    _lib.check(h.vitpe_debug_tail2_census(p(a), p(x), p(wpk), p(bp), p(gam), p(bet), p(xm), p(m2), p(r2), (0 if os.environ.get('T2_NOXN') else p(xn)), p(w1k), p(b1),
                                           p(w2k), p(b2), p(gp), p(hh), p(y), p(mo), p(ro), M, HID, p(cen), EXP,
                                           torch.cuda.current_stream().cuda_stream), "census")
 torch.cuda.synchronize()
 c = cen.cpu().numpy().reshape(nwg, 9, 16).astype(np.float64)
 act = c[:, :, 9] > 0
 t0 = c[:, :, 0].min()
+rt0, rt1 = c[:, :, 13][act], c[:, :, 14][act]
+life = (c[:, :, 9] - c[:, :, 0])[act]
+print(f"realtime: first wave start -> last wave end {(rt1.max() - rt0.min()) / 100:.2f} us; wave start after the first: median {np.median(rt0 - rt0.min()) / 100:.2f} us, "
+      f"max {(rt0 - rt0.min()).max() / 100:.2f} us; shader clock {np.median(life / np.maximum(rt1 - rt0, 1)) / 10:.2f} GHz")
 print(f"B={B} exp={EXP}: {nwg} workgroups; kernel span {c[:, :, 9].max() - t0:.0f} ticks of 10 ns; start spread median {np.median(c[:, :, 0] - t0):.0f} max {(c[:, :, 0] - t0).max():.0f}")
 names = ["dma+loads", "proj", "LN2 epi", "sync0", "period0", "periods1..", "sync last", "fc2 last", "out epi"]
 d = np.diff(c[:, :, :10], axis=2)

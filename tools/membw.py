@@ -44,5 +44,28 @@ def main():
               f" | read-reduce {tr:7.1f} us = {mb / tr:6.2f} TB/s")
 
 
+def write_heavy():
+    """The block-tail forward's mix: 25.6 MB read, 140.8 MB written per launch (x_mid, LN2(x_mid), out, h, g')."""
+    dev = "cuda"
+    n = 12_800_000 // 2 * 2
+    src = [torch.randn(n, device=dev).to(torch.bfloat16) for _ in range(8)]
+    dst = [torch.empty(11, n // 2, device=dev, dtype=torch.bfloat16) for _ in range(8)]
+    k = [0]
+
+    def mix():
+        i = k[0] % 8; k[0] += 1
+        dst[i].copy_(src[i].view(2, n // 2)[:1].expand(11, n // 2))      # 12.8 MB read, 140.8 MB written
+
+    def mix2():
+        i = k[0] % 8; k[0] += 1
+        dst[i][:3].copy_(src[i].view(2, n // 2)[:1].expand(3, n // 2))  # 12.8 MB read, 38.4 MB written (x_mid, xn, out only)
+
+    t = timeit(mix)
+    print(f"write-heavy: 12.8 MB in, 140.8 MB out  {t:7.1f} us = {(12.8 + 140.8) / t:6.2f} TB/s")
+    t = timeit(mix2)
+    print(f"write-heavy: 12.8 MB in,  38.4 MB out  {t:7.1f} us = {(12.8 + 38.4) / t:6.2f} TB/s")
+
+
 if __name__ == "__main__":
     main()
+    write_heavy()

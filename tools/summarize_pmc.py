@@ -48,7 +48,8 @@ PROBES = {
 }
 # what runs instead when a default is switched off (VITPE_ATTN_WIDE=0, VITPE_LNBWD2=0) or the PRE variant was not profiled
 FALLBACK = {
-    "attn_fwd": [["attn_fwd_kernel"]],
+    "attn_fwd": [["attn_fwd_kernel"], ["attn_core_fwd_kernel"]],     # (ViT-B/16 geometry: the attention core is the "attn" probe)
+    "attn_bwd": [["attn_core_bwd_kernel"]],
     "dgrad_qkv_ln1_bwd": [["gemm_panel_kernel"]],
     "block_tail_bwd": [["block_tail2_bwd_kernel"]],
 }
@@ -80,10 +81,14 @@ def main():
     ap.add_argument("root")
     ap.add_argument("tag")
     ap.add_argument("--round", default="03")
-    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--config", default="cifar", choices=["cifar", "imnet"])
+    ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--pos_encoding", default="rope-axial")
     ap.add_argument("--dtype", default="bf16")
     args, _ = ap.parse_known_args()
+    if args.batch is None:
+        args.batch = 512 if args.config == "cifar" else 64
+    suffix = "" if args.config == "cifar" else "|" + args.config
     F, W, S = (load(args.root, f"{args.tag}_pmc_{n}") for n in ("fetch", "write", "sq"))
     path = os.path.join(REPO, "profiles", f"r{args.round}_pmc.json")
     doc = {"entries": {}}
@@ -127,7 +132,7 @@ def main():
         lc, la = med(sq, "SQ_LDS_BANK_CONFLICT"), med(sq, "SQ_LDS_IDX_ACTIVE")
         if la and lc is not None:
             ent["lds_bank_conflict_frac"] = round(lc / la, 4)
-        doc["entries"][f"{probe}|B{args.batch}|{args.pos_encoding}|{args.dtype}"] = ent
+        doc["entries"][f"{probe}|B{args.batch}|{args.pos_encoding}|{args.dtype}{suffix}"] = ent
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as f:
         json.dump(doc, f, indent=1, sort_keys=True)

@@ -33,9 +33,6 @@
 #include <type_traits>
 #include <stdlib.h>
 
-#ifndef T2_NT_HID
-#define T2_NT_HID true
-#endif
 #ifndef T2_RB
 #define T2_RB 6
 #endif
@@ -87,10 +84,31 @@ VITPE_DEV float t2_xg_sum(float v) {
   return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
+// Output rows are written with BUFFER stores: (descriptor of the workgroup's rows of the tensor, byte offset of the lane's
+// row) instead of a pointer, so that the cache policy of every tensor is a compile-time choice (`aux`: 0 = write-back L2,
+// 2 = nt, 16 = sc1: written through the L2 as it goes, nothing left for the end-of-kernel write-back).
+#ifndef T2_AUX_HID
+#define T2_AUX_HID 2      // h, g', LayerNorm2 output, du: read again by a LATER kernel only (weight gradients / backward)
+#endif
+#ifndef T2_AUX_ROW
+#define T2_AUX_ROW 0      // x_mid, out, da, dx: the next kernel's input
+#endif
+struct T2Row {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int off;   // bytes
+  VITPE_DEV T2Row operator+(int elems) const { return T2Row{rsrc, off + 2 * elems}; }
+};
+// rows [row0, ...) of a [*, ld] bf16 tensor; the lane's row `row` >= row0 (wave-uniform base, 32-bit offsets)
+VITPE_DEV T2Row t2_row(void* base, int row0, int row, int ld) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<bf16*>(base) + (size_t)row0 * ld, 0, 0x7fffffff, 0x00020000);
+  return T2Row{r, (row - row0) * ld * 2};
+}
+typedef __attribute__((ext_vector_type(4))) unsigned t2_u32x4;
+
 // 16-B store of a tile pair: lane (c, g) holds features 16nt + 4g + r (r < 4) of token c for two adjacent tiles; one
 // v_permlane16_swap per dword gives every lane 8 CONTIGUOUS features (see attn.hip)
-template <bool NONTEMPORAL>
-VITPE_DEV void t2_store_pair(bf16* rowp, int nt0, int g, const f32x4& o0, const f32x4& o1) {
+template <int AUX>
+VITPE_DEV void t2_store_pair(const T2Row& row, int nt0, int g, const f32x4& o0, const f32x4& o1) {
   uint32_t lo[2], hi[2];
 #pragma unroll
   for (int w2 = 0; w2 < 2; ++w2) {
@@ -101,9 +119,7 @@ VITPE_DEV void t2_store_pair(bf16* rowp, int nt0, int g, const f32x4& o0, const 
     lo[w2] = r[0]; hi[w2] = r[1];
   }
   const int f0 = 16 * (nt0 + (g & 1)) + 8 * (g >> 1);
-  const Chunk16 v = {lo[0], lo[1], hi[0], hi[1]};
-  if (NONTEMPORAL) __builtin_nontemporal_store(v, reinterpret_cast<Chunk16*>(rowp + f0));
-  else *reinterpret_cast<Chunk16*>(rowp + f0) = v;
+  __builtin_amdgcn_raw_buffer_store_b128((t2_u32x4){lo[0], lo[1], hi[0], hi[1]}, row.rsrc, row.off + 2 * f0, 0, AUX);
 }
 
 // The same for gelu'(u), kept as IEEE half (round toward zero, v_cvt_pkrtz_f16_f32: one instruction per pair like the bf16
@@ -111,9 +127,8 @@ VITPE_DEV void t2_store_pair(bf16* rowp, int nt0, int g, const f32x4& o0, const 
 // to bf16 (8 significant bits) it put 2^-9 of relative noise on all of them, which the cancelling sums of the backward
 // (the shared polynomial-RPE coefficients: a sum over heads, layers and token pairs that mostly cancels) amplified to
 // 9 % of their max norm; 11 bits bring that back to what recomputing gelu'(u) from the bf16 u gives (round-3 log).
-typedef __attribute__((ext_vector_type(2))) _Float16 t2_half2;
-template <bool NONTEMPORAL>
-VITPE_DEV void t2_store_pair_f16(bf16* rowp, int nt0, int g, const f32x4& o0, const f32x4& o1) {
+template <int AUX>
+VITPE_DEV void t2_store_pair_f16(const T2Row& row, int nt0, int g, const f32x4& o0, const f32x4& o1) {
   uint32_t lo[2], hi[2];
 #pragma unroll
   for (int w2 = 0; w2 < 2; ++w2) {
@@ -123,9 +138,18 @@ VITPE_DEV void t2_store_pair_f16(bf16* rowp, int nt0, int g, const f32x4& o0, co
     lo[w2] = r[0]; hi[w2] = r[1];
   }
   const int f0 = 16 * (nt0 + (g & 1)) + 8 * (g >> 1);
-  const Chunk16 v = {lo[0], lo[1], hi[0], hi[1]};
-  if (NONTEMPORAL) __builtin_nontemporal_store(v, reinterpret_cast<Chunk16*>(rowp + f0));
-  else *reinterpret_cast<Chunk16*>(rowp + f0) = v;
+  __builtin_amdgcn_raw_buffer_store_b128((t2_u32x4){lo[0], lo[1], hi[0], hi[1]}, row.rsrc, row.off + 2 * f0, 0, AUX);
+}
+
+// The same 16-B row piece from the B FRAGMENT acc_to_frag made of a tile pair (lane (c, g): tile 2ks's features 4g .. 4g + 3
+// in dwords 0 - 1, tile 2ks + 1's in dwords 2 - 3): LayerNorm2's output row, written from what fc1 consumes.
+template <int AUX>
+VITPE_DEV void t2_store_frag(const T2Row& row, int ks, int g, const Frag<bf16>& f) {
+  const t2_u32x4 d = __builtin_bit_cast(t2_u32x4, f.v);
+  const auto r0 = __builtin_amdgcn_permlane16_swap(d[0], d[2], false, false);
+  const auto r1 = __builtin_amdgcn_permlane16_swap(d[1], d[3], false, false);
+  const int f0 = 16 * (2 * ks + (g & 1)) + 8 * (g >> 1);
+  __builtin_amdgcn_raw_buffer_store_b128((t2_u32x4){r0[0], r1[0], r0[1], r1[1]}, row.rsrc, row.off + 2 * f0, 0, AUX);
 }
 
 // acc[nt] += sum_ks W(nt, ks) x bf[ks] over NTL x KSL weight fragments in LDS (fragment (nt, ks) at wb + (nt * KSL + ks) * 512
@@ -238,7 +262,7 @@ VITPE_DEV void t2_step(const bf16* w1f, const bf16* w2f, const Frag<bf16> (&bf)[
 template <bool F1, bool G, bool F2, bool SAVE, int EXP = 0>
 VITPE_DEV void t2_substep(const bf16* w1f, const bf16* w2f, const Frag<bf16> (&bf)[T2_KS], f32x4 (&a1n)[2],
                           const f32x4 (&a1c)[2], const Frag<bf16>& hprev, Frag<bf16>& hnew, f32x4 (&acc2)[T2_NT],
-                          bf16* gpr, bf16* hr, int g) {
+                          const T2Row& gpr, const T2Row& hr, int g) {
   constexpr int NV = !G ? 0 : (F1 && F2) ? T2_NV : 2 * T2_NV;
   t2_step<F1, F2, NV, EXP>(w1f, w2f, bf, a1n, hprev, acc2, [&]() {
     if (!G) return;
@@ -258,8 +282,8 @@ VITPE_DEV void t2_substep(const bf16* w1f, const bf16* w2f, const Frag<bf16> (&b
       }
     }
     if (SAVE && !(EXP & 4)) {
-      t2_store_pair_f16<T2_NT_HID>(gpr, 0, g, gp[0], gp[1]);  // read again only in backward; IEEE half (see t2_store_pair_f16)
-      t2_store_pair<T2_NT_HID>(hr, 0, g, hh[0], hh[1]);
+      t2_store_pair_f16<T2_AUX_HID>(gpr, 0, g, gp[0], gp[1]);  // read again only in backward; IEEE half (see t2_store_pair_f16)
+      t2_store_pair<T2_AUX_HID>(hr, 0, g, hh[0], hh[1]);
     }
     hnew = acc_to_frag<bf16>(hh[0], hh[1]);
   });
@@ -294,7 +318,11 @@ __global__ __launch_bounds__(T2F_THREADS) void block_tail2_fwd_kernel(Tail2Args 
   unsigned long long acc_sync = 0, acc_fc1 = 0, acc_mix = 0, tm0 = 0;
   auto now = [&]() -> unsigned long long { return CENSUS ? __builtin_amdgcn_s_memtime() : 0ull; };
   auto stamp = [&](int slot) {
-    if (CENSUS && lane == 0 && wave < T2_WAVES) a.census[((size_t)blockIdx.x * T2_WAVES + wave) * 16 + slot] = __builtin_amdgcn_s_memtime();
+    if (CENSUS && lane == 0 && wave < T2_WAVES) {
+      a.census[((size_t)blockIdx.x * T2_WAVES + wave) * 16 + slot] = __builtin_amdgcn_s_memtime();
+      // slots 13 / 14: the chip-wide 100-MHz clock at the first and the last stamp (s_memtime counts per XCD)
+      if (slot == 0 || slot == 9) a.census[((size_t)blockIdx.x * T2_WAVES + wave) * 16 + (slot == 0 ? 13 : 14)] = __builtin_amdgcn_s_memrealtime();
+    }
   };
   stamp(0);
   auto dma1 = [&](const T* src_frag, int dst_frag) {
@@ -401,6 +429,7 @@ __global__ __launch_bounds__(T2F_THREADS) void block_tail2_fwd_kernel(Tail2Args 
 
     // ---- x_mid = x_in + proj + bias; LayerNorm2 statistics; xn -> B fragments of fc1 --------------------------------------
     T* const xmr = reinterpret_cast<T*>(a.xmid) + (size_t)rowc * D;
+    const T2Row xmrow = t2_row(a.xmid, 16 * tile0, rowc, D);
     const float invD = 1.0f / (float)D;
     {
       f32x4 acc[NT];
@@ -416,7 +445,8 @@ __global__ __launch_bounds__(T2F_THREADS) void block_tail2_fwd_kernel(Tail2Args 
         for (int r = 0; r < 4; ++r) { acc[nt][r] = to_f32(from_f32<T>(acc[nt][r] + (float)xres[nt][r])); s1 += acc[nt][r]; }   // values as stored
       }
   #pragma unroll
-      for (int nt = 0; nt < NT; nt += 2) t2_store_pair<false>(xmr, nt, g, acc[nt], acc[nt + 1]);
+      for (int nt = 0; nt < NT; nt += 2) t2_store_pair<T2_AUX_ROW>(xmrow, nt, g, acc[nt], acc[nt + 1]);
+      __builtin_amdgcn_sched_barrier(0);   // (x_mid's conversions stay here: floated past the variance pass they keep 48 more values alive)
       const float mean = t2_xg_sum(s1) * invD;
       float s2 = 0.f;
   #pragma unroll
@@ -425,29 +455,29 @@ __global__ __launch_bounds__(T2F_THREADS) void block_tail2_fwd_kernel(Tail2Args 
         for (int r = 0; r < 4; ++r) { const float d = acc[nt][r] - mean; s2 += d * d; }
       const float rstd = 1.0f / sqrtf(t2_xg_sum(s2) * invD + a.eps2);
       if (g == 0) { a.mean2[rowc] = mean; a.rstd2[rowc] = rstd; }
+      const T2Row xnr = t2_row(a.xn_out, 16 * tile0, rowc, D);
   #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        __builtin_amdgcn_sched_barrier(0);
-        const f32x4 gv = *reinterpret_cast<const f32x4*>(sPar + D + 16 * nt + 4 * g);
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(sPar + 2 * D + 16 * nt + 4 * g);
+      for (int ks = 0; ks < KS; ++ks) {
   #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[nt][r] = fmaf((acc[nt][r] - mean) * rstd, gv[r], bv[r]);
+        for (int nt = 2 * ks; nt < 2 * ks + 2; ++nt) {
+          __builtin_amdgcn_sched_barrier(0);
+          const f32x4 gv = *reinterpret_cast<const f32x4*>(sPar + D + 16 * nt + 4 * g);
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(sPar + 2 * D + 16 * nt + 4 * g);
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) acc[nt][r] = fmaf((acc[nt][r] - mean) * rstd, gv[r], bv[r]);
+        }
+        bf[ks] = acc_to_frag<T>(acc[2 * ks], acc[2 * ks + 1]);   // phi order inside the chunk
+        // (LayerNorm2's output row piece -- fc1's weight gradient reads it -- IS this fragment.  Writing the rows later, from
+        //  the fragments, a few slabs into the main loop instead of in this burst behind x_mid's was tried: no change, 63 us
+        //  either way; what the 12.8 MB cost shows only with HBM-resident operands, not in the waves' lifetimes: round-3 log)
+        if (a.xn_out != nullptr && (!HALFW || half == 0)) t2_store_frag<T2_AUX_HID>(xnr, ks, g, bf[ks]);
       }
-      if (a.xn_out != nullptr) {
-        T* xnr = reinterpret_cast<T*>(a.xn_out) + (size_t)rowc * D;
-  #pragma unroll
-        for (int nt = 0; nt < NT; nt += 2) t2_store_pair<true>(xnr, nt, g, acc[nt], acc[nt + 1]);
-      }
-  #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) bf[ks] = acc_to_frag<T>(acc[2 * ks], acc[2 * ks + 1]);   // phi order inside the chunk
     }
-
     // ---- the MLP branch: slab p = fc1 rows of the 64-wide chunk p | fc2 k chunk p - 1, two pipeline steps per slab ----------
     f32x4 acc2[NT];
   #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc2[nt] = *reinterpret_cast<const f32x4*>(sPar + 3 * D + 16 * nt + 4 * g);   // b2
-    T* const gpr = SAVE ? reinterpret_cast<T*>(a.gp_out) + (size_t)rowc * HID : nullptr;
-    T* const hr = SAVE ? reinterpret_cast<T*>(a.h_out) + (size_t)rowc * HID : nullptr;
+    const T2Row gpr = t2_row(a.gp_out, 16 * tile0, rowc, HID), hr = t2_row(a.h_out, 16 * tile0, rowc, HID);   // (unused unless SAVE)
     f32x4 aX[2], aY[2];          // fc1 accumulators of the even / odd 32-wide sub-chunk in flight
     Frag<T> hP, hQ;              // gelu fragments of the even / odd sub-chunk in flight
     const float* const b1l = sPar + 4 * D + 4 * g;
@@ -549,7 +579,7 @@ __global__ __launch_bounds__(T2F_THREADS) void block_tail2_fwd_kernel(Tail2Args 
 
     // ---- out = x_mid + fc2 + bias; statistics for the next block's LayerNorm1 ----------------------------------------------
     {
-      T* const outr = reinterpret_cast<T*>(a.out) + (size_t)rowc * D;
+      const T2Row outr = t2_row(a.out, 16 * tile0, rowc, D);
       float s1 = 0.f;
   #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -558,7 +588,7 @@ __global__ __launch_bounds__(T2F_THREADS) void block_tail2_fwd_kernel(Tail2Args 
         for (int r = 0; r < 4; ++r) { acc2[nt][r] = to_f32(from_f32<T>(acc2[nt][r] + rv[r])); s1 += acc2[nt][r]; }
       }
   #pragma unroll
-      for (int nt = 0; nt < NT; nt += 2) t2_store_pair<false>(outr, nt, g, acc2[nt], acc2[nt + 1]);
+      for (int nt = 0; nt < NT; nt += 2) t2_store_pair<T2_AUX_ROW>(outr, nt, g, acc2[nt], acc2[nt + 1]);
       if (a.mean_out != nullptr) {
         const float mean = t2_xg_sum(s1) * invD;
         float s2 = 0.f;
@@ -665,7 +695,7 @@ VITPE_DEV float t2_colsum8(const float (&t)[8], int c) {
 // rounded to the bf16 values stored to `orow`; the tile's dgamma / dbeta column sums (rows past M masked by `valid`) go to
 // the workgroup's LDS accumulators sAcc[0..191 | 192..383].  xrow / rrow: this lane's LayerNorm-input / residual row + 4g.
 VITPE_DEV void t2_ln_backward(f32x4 (&acc)[T2_NT], const bf16* xrow, const bf16* rrow, float mean, float rstd,
-                              const float* sGam, float* sAcc, int c, int g, float valid, bf16* orow) {
+                              const float* sGam, float* sAcc, int c, int g, float valid, const T2Row& orow) {
   constexpr int D = T2_D, NT = T2_NT;
   bf16x4 xmv[NT];
 #pragma unroll
@@ -715,7 +745,7 @@ VITPE_DEV void t2_ln_backward(f32x4 (&acc)[T2_NT], const bf16* xrow, const bf16*
     }
   }
 #pragma unroll
-  for (int nt = 0; nt < NT; nt += 2) t2_store_pair<false>(orow, nt, g, acc[nt], acc[nt + 1]);
+  for (int nt = 0; nt < NT; nt += 2) t2_store_pair<T2_AUX_ROW>(orow, nt, g, acc[nt], acc[nt + 1]);
 }
 
 // the last of the workgroup's `nactive` compute waves to arrive hands the LDS column sums to the global accumulators
@@ -881,13 +911,13 @@ __global__ __launch_bounds__(T2_THREADS) void block_tail2_bwd_kernel(Tail2BwdArg
     }
     t2_ln_backward(acc, reinterpret_cast<const T*>(a.x1) + (size_t)rowc * D + 4 * g,
                    reinterpret_cast<const T*>(a.dres1) + (size_t)rowc * D + 4 * g, a.mean1[rowc], a.rstd1[rowc], sGam1, sAcc1,
-                   c, g, valid, reinterpret_cast<T*>(const_cast<void*>(a.dy)) + (size_t)rowc * D);
+                   c, g, valid, t2_row(const_cast<void*>(a.dy), 16 * tile0, rowc, D));
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) bf[ks] = acc_to_frag<T>(acc[2 * ks], acc[2 * ks + 1]);
   }
 
   const T* const gpr = reinterpret_cast<const T*>(a.gp) + (size_t)rowc * HID + 16 * (g & 1) + 8 * (g >> 1);
-  T* const dur = reinterpret_cast<T*>(a.du) + (size_t)rowc * HID;
+  const T2Row dur = t2_row(a.du, 16 * tile0, rowc, HID);
   Chunk16 gq[2];                                 // gelu'(u) rows of sub-chunks t, t + 1 in flight (slot t & 1)
 #pragma unroll
   for (int t = 0; t < 2; ++t) gq[t] = *reinterpret_cast<const Chunk16*>(gpr + 32 * t);
@@ -904,7 +934,7 @@ __global__ __launch_bounds__(T2_THREADS) void block_tail2_bwd_kernel(Tail2BwdArg
     if (t + 2 < nsub) slot = *reinterpret_cast<const Chunk16*>(gpr + 32 * (t + 2));
 #pragma unroll
     for (int r = 0; r < 4; ++r) { d0[r] = a1c[0][r] * g0[r]; d1[r] = a1c[1][r] * g1[r]; }
-    t2_store_pair<true>(dur + 32 * t, 0, g, d0, d1);
+    t2_store_pair<T2_AUX_HID>(dur + 32 * t, 0, g, d0, d1);
     hnew = acc_to_frag<T>(d0, d1);
   };
   constexpr int NVB = 3, RB = T2_RB;    // VALU instructions of the G stage per MFMA (it is short: the step is matrix-pipe bound)
@@ -939,7 +969,7 @@ __global__ __launch_bounds__(T2_THREADS) void block_tail2_bwd_kernel(Tail2BwdArg
   // ---- LayerNorm2 backward + residual: dx_mid = dy + LayerNorm2'(dxn) ------------------------------------------------------------
   t2_ln_backward(acc2, reinterpret_cast<const T*>(a.xmid) + (size_t)rowc * D + 4 * g,
                  reinterpret_cast<const T*>(a.dy) + (size_t)rowc * D + 4 * g, a.mean2[rowc], a.rstd2[rowc], sGam, sAcc, c, g,
-                 valid, reinterpret_cast<T*>(a.dxmid) + (size_t)rowc * D);
+                 valid, t2_row(a.dxmid, 16 * tile0, rowc, D));
   // ---- da = dx_mid Wp ----------------------------------------------------------------------------------------------------------
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) bf[ks] = acc_to_frag<T>(acc2[2 * ks], acc2[2 * ks + 1]);
@@ -949,9 +979,9 @@ __global__ __launch_bounds__(T2_THREADS) void block_tail2_bwd_kernel(Tail2BwdArg
   wait_ready(Q + nchunk + 1);
   t2_gemm<NT, KS, 12>(sW + lane * 8, bf, accA);
   {
-    T* const dar = reinterpret_cast<T*>(a.da) + (size_t)rowc * D;
+    const T2Row dar = t2_row(a.da, 16 * tile0, rowc, D);
 #pragma unroll
-    for (int nt = 0; nt < NT; nt += 2) t2_store_pair<false>(dar, nt, g, accA[nt], accA[nt + 1]);
+    for (int nt = 0; nt < NT; nt += 2) t2_store_pair<T2_AUX_ROW>(dar, nt, g, accA[nt], accA[nt + 1]);
   }
   // ---- the last wave of the workgroup hands the column sums to the global accumulators ----------------------------------------
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1074,7 +1104,7 @@ __global__ __launch_bounds__(T2_THREADS) void ln_bwd2_kernel(LnBwd2Args a) {
   }
   t2_ln_backward(acc, reinterpret_cast<const T*>(a.x) + (size_t)rowc * D + 4 * g,
                  reinterpret_cast<const T*>(a.dres) + (size_t)rowc * D + 4 * g, a.mean[rowc], a.rstd[rowc], sGam, sAcc, c, g,
-                 valid, reinterpret_cast<T*>(a.dx) + (size_t)rowc * D);
+                 valid, t2_row(a.dx, 16 * tile0, rowc, D));
   t2_flush_colsums(sAcc, &sFin, ntile_wg, lane, a.dgamma, a.dbeta);
 }
 
