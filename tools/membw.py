@@ -66,6 +66,30 @@ def write_heavy():
     print(f"write-heavy: 12.8 MB in,  38.4 MB out  {t:7.1f} us = {(12.8 + 38.4) / t:6.2f} TB/s")
 
 
+def read_only():
+    """Pure reads through the library's debug streaming kernel (torch's reductions are far from the ceiling)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vit-rpe-rope_amd"))
+    from vitpe import _lib
+    h = _lib.debug_lib()
+    sink = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for mb in (51.2, 204.8, 1363.0):
+        n = int(mb * 1e6 / 4)
+        nbuf = max(2, min(12, int(3000 / mb)))
+        xs = [torch.randint(0, 2 ** 31 - 1, (n,), dtype=torch.int32, device="cuda") for _ in range(nbuf)]
+        for depth, wgs in ((4, 2048), (8, 2048), (8, 8192), (4, 16384)):
+            k = [0]
+
+            def rd():
+                i = k[0] % nbuf; k[0] += 1
+                _lib.check(h.vitpe_debug_read_bw(xs[i].data_ptr(), n * 4, depth, wgs, sink.data_ptr(), torch.cuda.current_stream().cuda_stream), "read_bw")
+
+            t = timeit(rd)
+            print(f"read {mb:7.1f} MB  depth {depth} x {wgs:5d} workgroups  {t:7.1f} us = {mb / t:5.2f} TB/s")
+        del xs
+
+
 if __name__ == "__main__":
     main()
     write_heavy()
+    read_only()

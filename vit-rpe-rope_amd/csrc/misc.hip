@@ -1056,4 +1056,29 @@ extern "C" int vitpe_selftest_mma(int dtype, const void* A, const void* Bt, cons
   VITPE_CHECK_LAUNCH();
 }
 
+// debug: what the memory system gives a kernel that ONLY reads -- `bytes` streamed with 16-B loads, `depth` independent
+// loads in flight per lane, one workgroup of 256 threads per 256 * depth * 16 B; nothing written unless the xor of all
+// words is a magic value (it never is).  tools/membw.py: the read ceiling the weight-gradient kernel is measured against.
+template <int DEPTH>
+__global__ __launch_bounds__(256) void read_bw_kernel(const uint4* __restrict__ src, long long nvec, unsigned* sink) {
+  const long long stride = (long long)gridDim.x * 256;
+  unsigned acc = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride * DEPTH) {
+    uint4 v[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) v[d] = (i + d * stride < nvec) ? src[i + d * stride] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) acc ^= v[d].x ^ v[d].y ^ v[d].z ^ v[d].w;
+  }
+  if (acc == 0x9E3779B9u) *sink = acc;
+}
+extern "C" int vitpe_debug_read_bw(const void* src, long long bytes, int depth, int workgroups, unsigned* sink, hipStream_t st) {
+  VITPE_REQUIRE(src && sink && bytes >= 16 && workgroups > 0 && (depth == 1 || depth == 4 || depth == 8));
+  const long long nvec = bytes / 16;
+  if (depth == 1) hipLaunchKernelGGL(read_bw_kernel<1>, dim3(workgroups), dim3(256), 0, st, (const uint4*)src, nvec, sink);
+  else if (depth == 4) hipLaunchKernelGGL(read_bw_kernel<4>, dim3(workgroups), dim3(256), 0, st, (const uint4*)src, nvec, sink);
+  else hipLaunchKernelGGL(read_bw_kernel<8>, dim3(workgroups), dim3(256), 0, st, (const uint4*)src, nvec, sink);
+  VITPE_CHECK_LAUNCH();
+}
+
 extern "C" int vitpe_abi_version(void) { return 4; }   // 4: + the wide attention forward entry points; block_tail2 keeps gelu'(u) as IEEE half
