@@ -124,6 +124,18 @@ int vitpe_attention_core_bwd(int dtype, const void* qkv, const void* dout, void*
                              int HD, int mode, const float* cos, const float* sin, const float* table,
                              const float* coeff, int grid, int degree, int coeff_per_head, float* dtable,
                              float* dcoeff, float* dfreqs, vitpe_stream_t stream);
+/* vitpe_attention_fused64_fwd: the reference's Attention.forward before self.proj (models/vit.py:47-88) at the ViT-B/16
+ * geometry (BASELINE config 5: hd = 64, N = 197) as ONE kernel -- the head's slice of the qkv projection, the rotation /
+ * bias, QK^T, softmax and .V per (image, head); q and k never leave the chip.  xn [B,N,D] T = LayerNorm1's output
+ * (D = 64 H); wqkv_packed = vitpe_pack_weight_frags(attn.qkv.weight [3D,D], kchunk 64, phi 0); qkv_out (nullable)
+ * [B,N,3D] T receives the raw projection, which is what vitpe_attention_core_bwd reads in training; out [B,N,D] T merged
+ * heads.  bf16, hd = 64, 193 <= N <= 208, H <= 16 (vitpe_attention_fused64_supported); else hipErrorNotSupported: run
+ * vitpe_linear + vitpe_attention_core_fwd.  PE arguments as vitpe_attention_core_fwd.                                   */
+int vitpe_attention_fused64_supported(int dtype, int N, int H, int HD);
+int vitpe_attention_fused64_fwd(int dtype, const void* xn, const void* wqkv_packed, void* qkv_out, void* out, int B,
+                                int N, int H, int HD, int mode, const float* cos, const float* sin,
+                                const float* table, const float* coeff, int grid, int degree, int coeff_per_head,
+                                vitpe_stream_t stream);
 
 /* ---- GEMMs ------------------------------------------------------------------------------
  * vitpe_gemm_nt: C[M,N] = epi(A[M,K] W[N,K]^T).  nn.Linear forward (vit.py:35,37; timm Mlp

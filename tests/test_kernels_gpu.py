@@ -822,6 +822,37 @@ def test_attention_core_matches_fused_kernel(K):
     assert rel_err(core.float().cpu(), fused.float().cpu()) < 2e-2
 
 
+@pytest.mark.parametrize("mode", ATTN_MODES)
+@pytest.mark.parametrize("D,H,B", [(128, 2, 3), (768, 12, 2)])
+def test_attention_fused64_fwd(K, mode, D, H, B):
+    """The one-kernel forward at the ViT-B/16 geometry (N = 197, hd = 64: qkv projection + PE + core per (image, head))
+    against the oracle, against the two launches it replaces (vitpe_linear + vitpe_attention_core_fwd) on the same operands,
+    and its raw-projection side output against the Linear's."""
+    G, bf = 14, torch.bfloat16
+    N, hd, G, xn, wqkv, dout, pe = attn_case(mode, D, H, B, seed=50, G=G)
+    wqkv = wqkv * (0.3 if D > 200 else 1.0)
+    assert N == 197 and hd == 64 and K.attention_fused64_supported(bf, N, H, hd)
+    ref, _, _ = oracle_attn(mode, xn, wqkv, dout, pe, H, "bf16")
+    t = device_pe(K, mode, pe, H, G)
+    xb = dev(xn, bf)
+    qkv_out = torch.full((B, N, 3 * D), float("nan"), device="cuda", dtype=bf)
+    out = K.attention_fused64_fwd(xb, K.pack_weight_frags(dev(wqkv), bf, 64, 0), H, t, qkv_out=qkv_out)
+    assert rel_err(out.float().cpu(), ref) < tol("bf16")
+    qkv2 = K.linear(xb.reshape(B * N, D), dev(wqkv, bf)).reshape(B, N, 3 * D)
+    assert rel_err(qkv_out.float().cpu(), qkv2.float().cpu()) < 8e-3          # other summation order, then one rounding
+    out2 = K.attention_core_fwd(qkv2, H, t)
+    assert rel_err(out.float().cpu(), out2.float().cpu()) < 1.5e-2
+    out3 = K.attention_fused64_fwd(xb, K.pack_weight_frags(dev(wqkv), bf, 64, 0), H, t)      # inference: no side output
+    assert torch.equal(out3.cpu(), out.cpu())
+
+
+def test_attention_fused64_unsupported_shapes(K):
+    bf = torch.bfloat16
+    assert K.attention_fused64_supported(bf, 197, 12, 64) and K.attention_fused64_supported(bf, 208, 2, 64)
+    assert not K.attention_fused64_supported(bf, 65, 6, 32) and not K.attention_fused64_supported(torch.float32, 197, 12, 64)
+    assert not K.attention_fused64_supported(bf, 209, 12, 64) and not K.attention_fused64_supported(bf, 192, 12, 64)
+
+
 def test_attention_core_unsupported_shape_is_an_error(K):
     from vitpe._lib import VitpeError
     from vitpe.kernels import PETables

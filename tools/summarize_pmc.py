@@ -48,7 +48,7 @@ PROBES = {
 }
 # what runs instead when a default is switched off (VITPE_ATTN_WIDE=0, VITPE_LNBWD2=0) or the PRE variant was not profiled
 FALLBACK = {
-    "attn_fwd": [["attn_fwd_kernel"], ["attn_core_fwd_kernel"]],     # (ViT-B/16 geometry: the attention core is the "attn" probe)
+    "attn_fwd": [["attn_fwd_kernel"], ["attn_fused64_fwd_kernel"], ["attn_core_fwd_kernel"]],   # (ViT-B/16 geometry: the one-kernel forward, or the core)
     "attn_bwd": [["attn_core_bwd_kernel"]],
     "dgrad_qkv_ln1_bwd": [["gemm_panel_kernel"]],
     "block_tail_bwd": [["block_tail2_bwd_kernel"]],

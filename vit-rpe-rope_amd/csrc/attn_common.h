@@ -31,6 +31,7 @@ struct AttnArgs {
   const float* ln_rstd;
   void* xn_out;
   unsigned long long* census;  // CENSUS instantiation only (vitpe_debug_attn_census): per-wave s_memtime stamps
+  void* qkv_out;       // fused hd-64 forward (attn_core.hip): nullable [B,N,3*H*HD] T, the raw projection for the backward
 };
 
 constexpr float LOG2E = 1.4426950408889634f;

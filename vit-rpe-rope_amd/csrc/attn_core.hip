@@ -17,6 +17,7 @@
 //   step 2 (key-tile jobs)  : q~ and dO in LDS, k~/v fragments from global: dV, dK
 // so that fp32 (the 1e-4 parity mode) fits as well: 2 x 61 KB at N=197.
 #include "attn_common.h"
+#include <type_traits>
 
 namespace vitpe {
 
@@ -159,6 +160,265 @@ __global__ __launch_bounds__(64 * NW) void attn_core_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int dt = 0; dt < C::NT; ++dt)
         st4(outp + (size_t)i * Dr + 16 * dt + 4 * g, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+    }
+  }
+}
+
+// =========================================================================================
+// Fused forward at the ViT-B/16 geometry (hd = 64, N <= 208: reference vit.py:47-88 at BASELINE config 5): the head's
+// slice of the qkv projection, the rotation and the core in ONE kernel -- q and k never exist outside the chip, the raw
+// projection is written once (optional: the backward reads it) and never read back.
+//
+// One workgroup per (image, head), 9 waves.  Waves 0..6 each own 32 tokens (two 16-token tiles): their x rows come
+// straight from global as B fragments (natural k order), the head's 12 weight tiles ({q, k, v} x 4 tiles of 16 output
+// features) as A fragments from LDS, where waves 7 and 8 put them by LDS-DMA from the fragment-packed copy
+// (vitpe_pack_weight_frags(attn.qkv.weight [3D, D], kchunk 64, phi 0): a 64-deep K chunk of one head is 24 fragments,
+// 8 contiguous KB per matrix), three chunk buffers, one barrier per chunk.  A weight fragment feeds two MFMAs (the
+// wave's two token tiles), so the LDS read traffic of the projection is 168 KB per chunk against 1.5 K cycles of MFMAs
+// per SIMD (a wave per 16-token tile would read twice that and be LDS-bound).  The accumulators hold [feature][token]
+// tiles (token on the lane): the rotate-half partner of a feature is the same register of the tile two over, so RoPE is
+// in-lane; K~ goes to LDS in the k order acc_to_frag gives the q fragments (the contraction over hd does not care), V
+// in natural order, q~ stays in registers as the B fragments of the wave's two query-tile jobs, which are the jobs
+// of attn_core_fwd_kernel.
+// =========================================================================================
+// 16-B store of two adjacent [feature][token] accumulator tiles (features 16 nt0 .. 16 nt0 + 31 of the lane's token row):
+// one v_permlane16_swap per dword gives every lane 8 CONTIGUOUS features (as tail2.hip's t2_store_pair)
+VITPE_DEV void f64_store_pair(bf16* rowp, int nt0, int g, const f32x4& o0, const f32x4& o1) {
+  uint32_t lo[2], hi[2];
+#pragma unroll
+  for (int w2 = 0; w2 < 2; ++w2) {
+    bf16x2 pa, pb;
+    pa[0] = (bf16)o0[2 * w2]; pa[1] = (bf16)o0[2 * w2 + 1];
+    pb[0] = (bf16)o1[2 * w2]; pb[1] = (bf16)o1[2 * w2 + 1];
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, pa), __builtin_bit_cast(uint32_t, pb), false, false);
+    lo[w2] = r[0]; hi[w2] = r[1];
+  }
+  const Chunk16 v = {lo[0], lo[1], hi[0], hi[1]};
+  *reinterpret_cast<Chunk16*>(rowp + 16 * (nt0 + (g & 1)) + 8 * (g >> 1)) = v;
+}
+
+constexpr int F64_CW = 7, F64_LW = 2, F64_NW = F64_CW + F64_LW;
+constexpr int F64_PIECES = 24, F64_NBUF = 3;
+
+template <int KM>
+__global__ __launch_bounds__(64 * F64_NW) void attn_fused64_fwd_kernel(AttnArgs a) {
+  using T = bf16;
+  constexpr int HD = 64, MT = 13;
+  using C = AttnCfg<T, HD, HD, MT, 1, 0>;
+  constexpr bool ROPE = (KM == KM_ROPE);
+  static_assert(32 * F64_CW >= C::VR, "the compute waves cover every row of the V tile");
+  __shared__ __attribute__((aligned(16))) T kt[C::QSZ];
+  __shared__ __attribute__((aligned(16))) T vt[C::HSZ];
+  __shared__ __attribute__((aligned(16))) T wb[F64_NBUF * F64_PIECES * 512];
+  __shared__ __attribute__((aligned(16))) float s_tab[KM == KM_RELATIVE ? C::TABLD : 4];
+  __shared__ __attribute__((aligned(16))) float s_coef[KM == KM_POLY ? C::PESZ : 4];
+
+  const int N = a.N, H = a.H, Dr = H * HD, P = N - 1;
+  const int b = blockIdx.x / H, hg = blockIdx.x % H;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int nchunk = Dr / 64;
+  const size_t hoff = (ROPE && a.mode == PE_ROPE_MIXED) ? (size_t)hg * P * (HD / 2) : 0;
+  const float* cosb = ROPE ? a.cos + hoff : nullptr;
+  const float* sinb = ROPE ? a.sin + hoff : nullptr;
+
+  stage_pe<C, KM>(a, hg, s_tab, s_coef, threadIdx.x, 64 * F64_NW);
+
+  if (wave >= F64_CW) {
+    // ---- loader waves: 12 fragments each per chunk (wave 7: q and half of k; wave 8: the rest) ---------------------------
+    const int lw = wave - F64_CW;
+    const T* const wsrc = reinterpret_cast<const T*>(a.wqkv) + lane * 8;
+    const int TD = Dr / 16;                      // 16-row tiles per matrix; 3 TD per K chunk in the packed copy
+    auto dma = [&](int kc, int buf) {
+#pragma unroll
+      for (int i = 0; i < F64_PIECES / F64_LW; ++i) {
+        const int p = (F64_PIECES / F64_LW) * lw + i, m = p >> 3, q8 = p & 7;
+        const T* src = wsrc + ((size_t)(kc * 3 * TD + m * TD + 4 * hg) * 2 + q8) * 512;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(wb + (buf * F64_PIECES + p) * 512), 16, 0, 0);
+      }
+    };
+    dma(0, 0);
+    if (nchunk > 1) dma(1, 1);
+    for (int kc = 0; kc < nchunk; ++kc) {
+      if (kc + 1 < nchunk) __builtin_amdgcn_s_waitcnt(0x0F7C);   // vmcnt(12): chunk kc has landed, chunk kc + 1 may be in flight
+      else __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0)
+      // (a bare s_barrier: __syncthreads() would drain vmcnt and with it the chunk in flight)
+      asm volatile("s_barrier" ::: "memory");                    // chunk kc visible; everybody has left chunk kc - 1's buffer
+      if (kc + 2 < nchunk) dma(kc + 2, (kc + 2) % F64_NBUF);
+    }
+    __syncthreads();                                             // (the barrier behind the K~ / V tiles)
+    return;
+  }
+
+  // ---- compute waves: projection of this wave's 32 tokens -----------------------------------------------------------------
+  int tok[2];
+  const T* xrow[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    tok[tt] = 32 * wave + 16 * tt + c;
+    xrow[tt] = reinterpret_cast<const T*>(a.xn) + ((size_t)b * N + min(tok[tt], N - 1)) * Dr + 8 * g;
+  }
+  f32x4 acc[3][4][2];
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) acc[m][j][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  Frag<T> cur[2][2], nxt[2][2];                  // [token tile][k step] of the chunk in work / the next one
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) nxt[tt][ks] = ld_frag(xrow[tt] + 32 * ks);
+  for (int kc = 0; kc < nchunk; ++kc) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) cur[tt][ks] = nxt[tt][ks];
+    asm volatile("s_barrier" ::: "memory");      // (this wave's reads of chunk kc - 1 fed MFMAs already issued: nothing to drain)
+    if (kc + 1 < nchunk) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) nxt[tt][ks] = ld_frag(xrow[tt] + 64 * (kc + 1) + 32 * ks);
+    }
+    const T* wf = wb + (kc % F64_NBUF) * F64_PIECES * 512 + lane * 8;
+    // 24 weight fragments per chunk in groups of three through two register sets: group n + 1 is read while group n feeds
+    // its six MFMAs (left alone the scheduler hoists all 24 reads to the top: 96 registers, 160 spilled)
+    {
+      constexpr int GS = 3, NG = 24 / GS;
+      Frag<T> wr[2][GS];
+      auto rd = [&](int gi, Frag<T> (&dst)[GS]) {
+#pragma unroll
+        for (int t = 0; t < GS; ++t) {
+          const int f = gi * GS + t, ks = f / 12, mj = f % 12;
+          dst[t] = ld_frag(wf + (mj * 2 + ks) * 512);
+        }
+      };
+      rd(0, wr[0]);
+#pragma unroll
+      for (int gi = 0; gi < NG; ++gi) {
+        if (gi + 1 < NG) rd(gi + 1, wr[(gi + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < GS; ++t) {
+          const int f = gi * GS + t, ks = f / 12, mj = f % 12;
+          mma(wr[gi & 1][t], cur[0][ks], acc[mj >> 2][mj & 3][0]);
+          mma(wr[gi & 1][t], cur[1][ks], acc[mj >> 2][mj & 3][1]);   // (the last wave's second tile is padding: computed anyway --
+                                                                     //  a second copy of this loop behind a branch cost 230 spills)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+
+  // ---- raw projection out (the values every later step sees are the bf16-rounded ones, as on the unfused path) ----------
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[m][j][tt][r] = to_f32(from_f32<T>(acc[m][j][tt][r]));
+  if (a.qkv_out != nullptr) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      // (the swaps pair lane groups: every lane takes part, rows past N write their clamped row's address -- row N - 1,
+      //  same values as that row's own lane: x was read from the clamped row)
+      T* qo = reinterpret_cast<T*>(a.qkv_out) + ((size_t)b * N + min(tok[tt], N - 1)) * 3 * Dr + hg * HD;
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) f64_store_pair(qo + (size_t)m * Dr, j, g, acc[m][j][tt], acc[m][j + 1][tt]);
+    }
+  }
+  // ---- rotation of q and k (rotate-half pairs (f, f + 32): tile j and tile j + 2, same register), class token excluded -----
+  if (ROPE) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      if (tok[tt] >= 1 && tok[tt] < N) {
+        const float* csr = cosb + (size_t)(tok[tt] - 1) * (HD / 2) + 4 * g;
+        const float* snr = sinb + (size_t)(tok[tt] - 1) * (HD / 2) + 4 * g;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f32x4 cv = *reinterpret_cast<const f32x4*>(csr + 16 * j), sv = *reinterpret_cast<const f32x4*>(snr + 16 * j);
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float lo = acc[m][j][tt][r], hi = acc[m][j + 2][tt][r];
+              acc[m][j][tt][r] = lo * cv[r] - hi * sv[r];
+              acc[m][j + 2][tt][r] = hi * cv[r] + lo * sv[r];
+            }
+        }
+      }
+    }
+  }
+  // ---- K~ (k order of the q fragments) and V (natural) -> LDS, rows past N zero; q~ -> B fragments ---------------------------
+  Frag<T> bq[2][C::HC];
+  const float qsc = a.scale * LOG2E;
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int row = 32 * wave + 16 * tt + c;
+    const float live = tok[tt] < N ? 1.f : 0.f;
+#pragma unroll
+    for (int cs = 0; cs < C::HC; ++cs) {
+      f32x4 klo = acc[1][2 * cs][tt], khi = acc[1][2 * cs + 1][tt], qlo = acc[0][2 * cs][tt], qhi = acc[0][2 * cs + 1][tt];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { klo[r] *= live; khi[r] *= live; qlo[r] *= qsc; qhi[r] *= qsc; }
+      if (row < C::NP) *reinterpret_cast<bf16x8*>(kt + row * C::LDH + 32 * cs + 8 * g) = acc_to_frag<T>(klo, khi).v;
+      bq[tt][cs] = acc_to_frag<T>(qlo, qhi);
+      pin_frag(bq[tt][cs]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      st4(vt + row * C::LDH + 16 * j + 4 * g, acc[2][j][tt][0] * live, acc[2][j][tt][1] * live, acc[2][j][tt][2] * live,
+          acc[2][j][tt][3] * live);
+  }
+  __syncthreads();
+
+  // ---- the core: this wave's two query tiles (attn_core_fwd_kernel's job) -------------------------------------------------
+  T* outp = reinterpret_cast<T*>(a.out) + (size_t)b * N * Dr + hg * HD;
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int it = 2 * wave + tt;
+    if (it >= MT) break;
+    const int i = 16 * it + c;
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 s[MT];
+    const float mx = logits_T<T, C, KM>(a, kt, bq[tt], s_tab, s_coef, 0, it, lane, s);
+    float l = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < MT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[jt][r] - mx);
+        s[jt][r] = p;
+        l += p;
+      }
+    l = xg_sum(l);
+    f32x4 o[C::NT];
+#pragma unroll
+    for (int dt = 0; dt < C::NT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sc = 0; sc < C::SC; ++sc) {
+      const Frag<T> bp = acc_to_frag<T>(s[2 * sc], (2 * sc + 1 < MT) ? s[(2 * sc + 1 < MT) ? 2 * sc + 1 : 0] : z4);
+#pragma unroll
+      for (int dt = 0; dt < C::NT; ++dt)
+        mma(ld_frag_tr(vt, C::LDH, 32 * sc + 4 * g, 32 * sc + 16 + 4 * g, 16 * dt), bp, o[dt]);
+    }
+    const float inv = __builtin_amdgcn_rcpf(l);
+#pragma unroll
+    for (int dt = 0; dt < C::NT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[dt][r] *= inv;
+    if (i < N) {   // (the swap pairs lanes of the same token: both sides of a pair are in or out together)
+#pragma unroll
+      for (int dt = 0; dt < C::NT; dt += 2) f64_store_pair(outp + (size_t)i * Dr, dt, g, o[dt], o[dt + 1]);
     }
   }
 }
@@ -569,6 +829,34 @@ extern "C" int vitpe_attention_core_fwd(int dtype, const void* qkv, void* out, i
   a.B = B; a.N = N; a.H = H; a.mode = mode; a.grid = grid; a.degree = degree; a.coeff_per_head = coeff_per_head;
   a.scale = 1.0f / sqrtf((float)HD);
   return dispatch_core(false, dtype, HD, a, stream);
+}
+
+// The fused forward at hd = 64 (attn_fused64_fwd_kernel): bf16, 193 <= N <= 208 (13 token tiles), H <= 16 heads of 64.
+extern "C" int vitpe_attention_fused64_supported(int dtype, int N, int H, int HD) {
+  return dtype == 1 && HD == 64 && (N + 15) / 16 == 13 && H >= 1 && H <= CORE_HMAX;
+}
+
+extern "C" int vitpe_attention_fused64_fwd(int dtype, const void* xn, const void* wqkv_packed, void* qkv_out, void* out, int B,
+                                           int N, int H, int HD, int mode, const float* cos, const float* sin,
+                                           const float* table, const float* coeff, int grid, int degree, int coeff_per_head,
+                                           hipStream_t stream) {
+  VITPE_REQUIRE(xn && wqkv_packed && out && B >= 0);
+  if (!vitpe_attention_fused64_supported(dtype, N, H, HD)) return (int)hipErrorNotSupported;
+  VITPE_REQUIRE(core_check_pe(mode, cos, sin, table, coeff, N, H, grid, degree));
+  if (B == 0) return 0;
+  AttnArgs a{};
+  a.xn = xn; a.wqkv = wqkv_packed; a.qkv_out = qkv_out; a.out = out; a.cos = cos; a.sin = sin; a.table = table; a.coeff = coeff;
+  a.B = B; a.N = N; a.H = H; a.mode = mode; a.grid = grid; a.degree = degree; a.coeff_per_head = coeff_per_head;
+  a.scale = 1.0f / sqrtf((float)HD);
+  const dim3 grid_((unsigned)(B * H)), block(64 * F64_NW);
+  switch (mode) {
+    case PE_RELATIVE: hipLaunchKernelGGL((attn_fused64_fwd_kernel<KM_RELATIVE>), grid_, block, 0, stream, a); break;
+    case PE_POLY: hipLaunchKernelGGL((attn_fused64_fwd_kernel<KM_POLY>), grid_, block, 0, stream, a); break;
+    case PE_ROPE_AXIAL:
+    case PE_ROPE_MIXED: hipLaunchKernelGGL((attn_fused64_fwd_kernel<KM_ROPE>), grid_, block, 0, stream, a); break;
+    default: hipLaunchKernelGGL((attn_fused64_fwd_kernel<KM_PLAIN>), grid_, block, 0, stream, a); break;
+  }
+  VITPE_CHECK_LAUNCH();
 }
 
 extern "C" int vitpe_attention_core_bwd(int dtype, const void* qkv, const void* dout, void* dqkv, int B, int N, int H,

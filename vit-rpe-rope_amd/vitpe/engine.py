@@ -74,6 +74,11 @@ class TrainEngine:
         # the 32x32-tile forward kernel (csrc/attn32.hip) for the benchmark geometry; VITPE_ATTN_WIDE=0: the 16x16-tile one
         self.attn_wide = (self.attn_fused and K.fused_attention_wide_supported(self.T, self.N, self.D, self.D // self.H)
                           and os.environ.get("VITPE_ATTN_WIDE", "1") == "1")
+        # ViT-B/16 geometry (hd = 64, N = 197): qkv projection + PE + core in one kernel (csrc/attn_core.hip,
+        # attn_fused64_fwd_kernel); the raw projection is still written once in training -- the core backward reads it.
+        # VITPE_ATTN_FUSED64=0: vitpe_linear + vitpe_attention_core_fwd
+        self.attn_fused64 = (not self.attn_fused and os.environ.get("VITPE_ATTN_FUSED64", "1") == "1"
+                             and K.attention_fused64_supported(self.T, self.N, self.H, self.D // self.H))
         if not self.attn_fused:   # the LayerNorm / MLP fusions hang off the fused attention kernels' geometry
             self.fuse_ln = self.fuse_ln_bwd = False
         # block tail (attn.proj + residual + LayerNorm2 + MLP branch) as one kernel per direction: a wave per 16-token
@@ -162,7 +167,7 @@ class TrainEngine:
                 if self.attn_wide:
                     add(qkv, 6, HDh)
             else:
-                add(qkv, 0, 0)
+                add(qkv, 0, 0, *((2, 64) if self.attn_fused64 else ()))
             if self.tail2:
                 add(proj, 2, 192, *((5, 192) if gen2 else (0, 0)))
                 add(fc1, 3, 192, *((5, 32) if gen2 else (0, 0)))
@@ -360,6 +365,9 @@ class TrainEngine:
                             mean=a["m1"], rstd=a["r1"])
             if self.attn_fused:
                 self._attn_fwd(a["xn1"], blk, a["a"])
+            elif self.attn_fused64:
+                K.attention_fused64_fwd(a["xn1"], self.Fr(blk.attn.qkv.weight), self.H, self.pe,
+                                        qkv_out=(self.qkv_l[l] if self._save_hidden else None), out=a["a"])
             else:
                 K.linear(a["xn1"].view(M, D), self.Sh(blk.attn.qkv.weight), None, out=self.qkv_l[l].view(M, 3 * D))
                 K.attention_core_fwd(self.qkv_l[l], self.H, self.pe, out=a["a"])
@@ -801,9 +809,15 @@ class TrainEngine:
                                fns=[bwd(l) for l in range(self.Lyr)], flop=2 * (qkv_flop + attn_core_flop),
                                bytes=(2 + 3) * M * D * es))     # xn, dout in; d_qkv out
         else:
-            probes.append(dict(name="attn_fwd", kernel="attn_core_fwd_kernel (RoPE+QK^T+softmax+AV per (image, head))",
-                               fns=[(lambda l=l: K.attention_core_fwd(self.qkv_l[l], Hh, self.pe, out=self.act[l]["a"]))
-                                    for l in range(self.Lyr)], flop=attn_core_flop, bytes=4 * M * D * es))
+            if self.attn_fused64:   # what the step runs: projection + PE + core in one kernel, raw projection written once
+                probes.append(dict(name="attn_fwd", kernel="attn_fused64_fwd_kernel (QKV-project+RoPE+QK^T+softmax+AV per (image, head), + raw qkv out)",
+                                   fns=[(lambda l=l: K.attention_fused64_fwd(self.act[l]["xn1"], self.Fr(mdl.blocks[l].attn.qkv.weight), Hh,
+                                                                             self.pe, qkv_out=self.qkv_l[l], out=self.act[l]["a"]))
+                                        for l in range(self.Lyr)], flop=qkv_flop + attn_core_flop, bytes=(1 + 3 + 1) * M * D * es))
+            else:
+                probes.append(dict(name="attn_fwd", kernel="attn_core_fwd_kernel (RoPE+QK^T+softmax+AV per (image, head))",
+                                   fns=[(lambda l=l: K.attention_core_fwd(self.qkv_l[l], Hh, self.pe, out=self.act[l]["a"]))
+                                        for l in range(self.Lyr)], flop=attn_core_flop, bytes=4 * M * D * es))
             probes.append(dict(name="attn_bwd", kernel="attn_core_bwd_kernel",
                                fns=[(lambda l=l: K.attention_core_bwd(self.qkv_l[l], self.dx_mid[l], Hh, self.pe,
                                                                       out=self.dqkv_l[l], **self.pe_grads))

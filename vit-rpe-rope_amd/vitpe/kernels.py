@@ -427,6 +427,27 @@ def attention_core_fwd(qkv, num_heads, pe: PETables, out=None):
     return o
 
 
+def attention_fused64_supported(dtype, N, num_heads, HD) -> bool:
+    return bool(lib().vitpe_attention_fused64_supported(dtype_code(dtype), int(N), int(num_heads), int(HD)))
+
+
+def attention_fused64_fwd(xn, wqkv_pk, num_heads, pe: PETables, qkv_out=None, out=None):
+    """qkv projection + PE + attention core in one kernel at hd = 64 (ViT-B/16 geometry): xn [B,N,D] layer-normed tokens,
+    wqkv_pk = pack_weight_frags(qkv.weight [3D,D], dtype, 64, 0); qkv_out (optional) [B,N,3D] gets the raw projection
+    for attention_core_bwd.  -> merged heads [B,N,D]."""
+    require_device(xn, wqkv_pk, qkv_out, out, pe.cos, pe.sin, pe.table, pe.coeff)
+    B, N, D = xn.shape
+    HD = D // num_heads
+    assert wqkv_pk.numel() == 3 * D * D and wqkv_pk.dtype == xn.dtype
+    if qkv_out is not None:
+        assert qkv_out.shape == (B, N, 3 * D) and qkv_out.dtype == xn.dtype and qkv_out.is_contiguous()
+    o = out if out is not None else torch.empty_like(xn)
+    check(lib().vitpe_attention_fused64_fwd(dtype_code(xn.dtype), ptr(xn), ptr(wqkv_pk), ptr(qkv_out), ptr(o), B, N, num_heads,
+                                            HD, pe.code, ptr(pe.cos), ptr(pe.sin), ptr(pe.table), ptr(pe.coeff), pe.grid,
+                                            pe.degree, int(pe.coeff_per_head), stream_ptr()), "vitpe_attention_fused64_fwd")
+    return o
+
+
 def attention_core_bwd(qkv, dout, num_heads, pe: PETables, dtable=None, dcoeff=None, dfreqs=None, out=None):
     """-> dqkv [B,N,3D]; PE-parameter gradients accumulated into dtable/dcoeff/dfreqs."""
     require_device(qkv, dout, dtable, dcoeff, dfreqs, out)
