@@ -479,6 +479,41 @@ def test_wgrad_group_window_mode_many_blocks(K, dt):
         assert rel_err(dw.cpu(), 2 * rw) < tol(dt)
 
 
+@pytest.mark.parametrize("case", ["one problem", "few blocks", "table", "windows", "ragged rows"])
+def test_wgrad_group_wide_blocks(K, case):
+    """Lists whose every problem has N % 192 == 0 and K % 384 == 0 (bf16, plain X) run on the 192 x 384-block kernel
+    (LDS-DMA staging, 96 x 96 wave tiles): stream-K, table, window placements; bias on / off; a partial last stage (rows
+    past M are zeroed in LDS); repeated launches accumulate; every problem against dY^T X with per-row checks."""
+    shapes = {"one problem": [(640, 192, 384, True)],
+              "few blocks": [(64 * 9, 384, 768, True), (64 * 9, 192, 384, False), (64 * 5, 768, 768, True)],
+              "table": [(64 * 40, 768, 768, True), (64 * 40, 2304, 768, False), (64 * 40, 768, 3072, True), (64 * 40, 3072, 768, True)],
+              "windows": [(64 * 6, 2304, 768, False), (64 * 6, 768, 768, True), (64 * 6, 3072, 768, True), (64 * 6, 768, 3072, True)] * 6,
+              "ragged rows": [(64 * 3 + 17, 384, 768, True), (1, 192, 384, True), (130, 576, 384, False)]}[case]
+    probs, refs = [], []
+    for i, (M, N, K_, bias) in enumerate(shapes):
+        dy, x = rnd(M, N, seed=310 + i), rnd(M, K_, seed=350 + i)
+        dw = torch.zeros(N, K_, device="cuda")
+        db = torch.zeros(N, device="cuda") if bias else None
+        probs.append((dev(dy, torch.bfloat16), dev(x, torch.bfloat16), dw, db))
+        refs.append((q(dy, "bf16").t() @ q(x, "bf16"), q(dy, "bf16").sum(0)))
+    if case == "windows":
+        assert sum((N // 192) * (K_ // 384) for _, N, K_, _ in shapes) >= 2 * 256
+    grp = K.WgradGroup(probs)
+    grp.launch()
+    for (dy, x, dw, db), (rw, rb) in zip(probs, refs):
+        assert rel_err(dw.cpu(), rw) < tol("bf16"), tuple(dw.shape)
+        worst = max(rel_err(dw[r_].cpu(), rw[r_]) for r_ in (0, 95, 96, dw.shape[0] - 1))
+        assert worst < 2 * tol("bf16"), (tuple(dw.shape), worst)
+        assert rel_err(dw[:, -97:].cpu(), rw[:, -97:]) < 2 * tol("bf16")
+        if db is not None:
+            assert rel_err(db.cpu(), rb) < tol("bf16"), tuple(dw.shape)
+    grp.launch()   # accumulates
+    for (dy, x, dw, db), (rw, rb) in zip(probs, refs):
+        assert rel_err(dw.cpu(), 2 * rw) < tol("bf16")
+        if db is not None:
+            assert rel_err(db.cpu(), 2 * rb) < tol("bf16")
+
+
 def test_wgrad_group_range_major_windows_model_sized_list(K):
     """A list the size of the CIFAR model's (24 nn.Linear problems, 72 blocks of 192 x 192) with enough rows for seven row
     ranges per block: 504 (range, block) pairs dealt range-major over two rounds of the chip, a partial flush per pair."""

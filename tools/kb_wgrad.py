@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""The grouped weight-gradient launch on the two problem lists the train steps hand it, bf16:
+CIFAR ViT (d = 192, M = 33 280: all 24 nn.Linear of the model + patch embed) and ViT-B/16 (d = 768, M = 12 608: the
+24 nn.Linear of six layers = one of the step's two launches).   python tools/kb_wgrad.py"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vit-rpe-rope_amd"))
+from vitpe import _lib, kernels as K
+
+T = torch.bfloat16
+r = lambda *s: (torch.randn(*s, device="cuda") * 0.1).to(T)  # noqa: E731
+z = lambda *s: torch.zeros(*s, device="cuda")  # noqa: E731
+
+
+def timeit(fn, iters=20, warm=4):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+
+
+for name, M, D, layers in (("CIFAR d=192, 6 layers", 512 * 65, 192, 6), ("ViT-B/16 d=768, 6 of 12 layers", 64 * 197, 768, 6)):
+    probs, flop, byts = [], 0, 0
+    for _ in range(layers):   # distinct operands per layer, as in the step
+        for N, Kd in ((3 * D, D), (D, D), (4 * D, D), (D, 4 * D)):
+            probs.append((r(M, N), r(M, Kd), z(N, Kd), z(N) if N != 3 * D else None))
+            flop += 2 * M * N * Kd
+            byts += (M * N + M * Kd) * 2
+    grp = K.WgradGroup(probs)
+    for wide in (1, 0, 1, 0):   # (the CIFAR list never qualifies for the 192 x 384-block kernel: both rows the same kernel)
+        _lib.debug_lib().vitpe_debug_set_wgrad_wide(wide)
+        us = timeit(grp.launch)
+        print(f"{name:32s} wide blocks {'on ' if wide else 'off'} {us:8.1f} us = {flop / us / 1e6:6.0f} TF   operands {byts / 1e6:7.0f} MB = "
+              f"{byts / us / 1e6:5.2f} TB/s if read once")
+    _lib.debug_lib().vitpe_debug_set_wgrad_wide(1)

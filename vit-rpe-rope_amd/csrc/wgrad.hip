@@ -52,6 +52,7 @@ struct WgArgs {
   int use_table;   // 1: workgroup i runs table[i] = (problem << 11 | block << 5 | row range), 0xFFFF = idle; 2: window mode
   int nranges;     // row ranges per block in table mode (window mode: of the blocks of the last, partial window)
   int full_rounds, total_blocks;   // window mode (use_table == 2): whole windows of gridDim.x blocks; blocks in the list
+  int bk;          // block width along K: 192 (wgrad_group_kernel) or 384 (wgrad_wide_kernel)
   int range_major; // window mode, lists below two windows: EVERY block is cut into nranges row ranges, the (range, block) pairs
                    // are dealt range-major in full_rounds windows (73 blocks x 7 ranges = 511 of 512 slots: two balanced rounds)
   unsigned long long* census;   // CENSUS build only (vitpe_debug_wgrad_census): s_memtime stamps
@@ -70,7 +71,9 @@ template <> struct WgLayout<bf16> {
     return r * LD + ((((cc >> 1) ^ s)) << 4) + ((cc & 1) << 3);
   }
   // transposed fragment: rows rb0..rb0+3 / rb1..rb1+3 (rb multiple of 4), 16 columns at c0 (multiple of 16)
-  static __device__ __forceinline__ Frag<bf16> tr(const bf16* tile, int rb0, int rb1, int c0) {
+  static __device__ __forceinline__ Frag<bf16> tr(const bf16* tile, int rb0, int rb1, int c0) { return tr_ld<LD>(tile, rb0, rb1, c0); }
+  template <int LD>
+  static __device__ __forceinline__ Frag<bf16> tr_ld(const bf16* tile, int rb0, int rb1, int c0) {
     const int i = threadIdx.x & 15, q = i >> 2, p = i & 3;
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     const int r0 = rb0 + q, r1 = rb1 + q;
@@ -92,6 +95,65 @@ template <> struct WgLayout<float> {  // exact-fp32 parity mode: padded rows, sc
     return ld_frag_tr(tile, LD, rb0, rb1, c0);
   }
 };
+
+// Work assignment shared by the two kernels: calls run(u0, uend) for every contiguous run of work units (one unit = one
+// (output block, 64-row stage)) this workgroup owns.
+template <class RunFn>
+VITPE_DEV void wg_dispatch(const WgArgs& a, RunFn run) {
+  // Window mode (big lists: at least two windows of gridDim.x blocks): every workgroup takes WHOLE blocks, one per round;
+  // round r runs the gridDim.x consecutive blocks of window r at the same time and gives each XCD (workgroup id % 8) a
+  // contiguous eighth of them -- with the n-blocks of a problem adjacent, the workgroups of an XCD then walk the same token
+  // rows of the same dY / X column blocks in step and the second reader is served by that XCD's L2.  (Stream-K hands
+  // every CU a contiguous run of units instead: the blocks alive at one time are far apart in the list, nothing is shared
+  // and every stage of every block comes through the fabric -- 11.4 GB per launch on the ViT-B/16 list for 1.9 GB of
+  // operands.)  One flush per block; the last, partial window is cut into row ranges so that it still fills the chip.
+  if (a.use_table == 2) {
+    const int G = gridDim.x, idx = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    for (int r = 0; r <= a.full_rounds; ++r) {
+      int gb, rng = 0, R = 1;
+      if (a.range_major) {
+        if (r == a.full_rounds) break;
+        const int vb = r * G + idx;
+        R = a.nranges;
+        rng = vb / a.total_blocks;
+        gb = rng < R ? vb - rng * a.total_blocks : a.total_blocks;
+      } else if (r < a.full_rounds) {
+        gb = r * G + idx;
+      } else {
+        R = a.nranges;
+        gb = a.full_rounds * G + idx / R;
+        rng = idx % R;
+      }
+      if (gb >= a.total_blocks) continue;
+      int pi = 0, b0 = 0;
+      for (int i = 0; i < a.nprob; ++i) {
+        const int nb = a.p[i].nbn * ((a.p[i].K + a.bk - 1) / a.bk);
+        if (gb >= b0 + nb) { b0 += nb; pi = i + 1; } else break;
+      }
+      const WgProb& P = a.p[pi];
+      const int spr = (P.stages + R - 1) / R;
+      const int ub = P.unit0 + (gb - b0) * P.stages;
+      const int u0 = ub + min(P.stages, rng * spr), uend = ub + min(P.stages, (rng + 1) * spr);
+      if (u0 < uend) run(u0, uend);
+    }
+    return;
+  }
+  int u0, uend;
+  if (a.use_table == 1) {
+    const unsigned ent = a.table[blockIdx.x];
+    if (ent == 0xFFFFu) return;
+    const WgProb& P = a.p[ent >> 11];
+    const int blk = (int)((ent >> 5) & 0x3Fu), rng = (int)(ent & 0x1Fu);
+    const int spr = (P.stages + a.nranges - 1) / a.nranges;
+    u0 = P.unit0 + blk * P.stages + min(P.stages, rng * spr);
+    uend = P.unit0 + blk * P.stages + min(P.stages, (rng + 1) * spr);
+  } else {
+    u0 = blockIdx.x * a.units_per_wg;
+    uend = min(a.total_units, u0 + a.units_per_wg);
+  }
+  if (u0 >= uend) return;
+  run(u0, uend);
+}
 
 // LNX: compiled with the LayerNorm-operand path (x_op).  A separate instantiation: its two statistics loads per staged
 // X chunk double the VMEM instruction count of a stage, and this kernel lives on the vector-memory path (measured:
@@ -130,7 +192,7 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
     s.xgamma = P.xgamma; s.xbeta = P.xbeta; s.xop = P.xop;
     s.stage = ub - blk * P.stages;
     s.n0 = (blk % P.nbn) * WG_BLK;
-    s.k0 = (blk / P.nbn) * WG_BLK;
+    s.k0 = (blk / P.nbn) * a.bk;
   };
 
   const Chunk16 zero = {0u, 0u, 0u, 0u};
@@ -283,59 +345,171 @@ __global__ __launch_bounds__(768) void wgrad_group_kernel(WgArgs a) {
     }
   };
 
-  // Window mode (big lists: at least two windows of gridDim.x blocks): every workgroup takes WHOLE blocks, one per round;
-  // round r runs the gridDim.x consecutive blocks of window r at the same time and gives each XCD (workgroup id % 8) a
-  // contiguous eighth of them -- with the n-blocks of a problem adjacent, the workgroups of an XCD then walk the same token
-  // rows of the same dY / X column blocks in step and the second reader is served by that XCD's L2.  (Stream-K hands
-  // every CU a contiguous run of units instead: the blocks alive at one time are far apart in the list, nothing is shared
-  // and every stage of every block comes through the fabric -- 11.4 GB per launch on the ViT-B/16 list for 1.9 GB of
-  // operands.)  One flush per block; the last, partial window is cut into row ranges so that it still fills the chip.
-  if (a.use_table == 2) {
-    const int G = gridDim.x, idx = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-    for (int r = 0; r <= a.full_rounds; ++r) {
-      int gb, rng = 0, R = 1;
-      if (a.range_major) {
-        if (r == a.full_rounds) break;
-        const int vb = r * G + idx;
-        R = a.nranges;
-        rng = vb / a.total_blocks;
-        gb = rng < R ? vb - rng * a.total_blocks : a.total_blocks;
-      } else if (r < a.full_rounds) {
-        gb = r * G + idx;
+  wg_dispatch(a, run);
+}
+
+// =========================================================================================
+// Wide blocks: 192 (dY columns) x 384 (X columns) per workgroup, 8 waves as 2 x 4 with 96 x 96 wave tiles, for lists whose
+// every problem has N % 192 == 0 and K % 384 == 0 (ViT-B/16: K in {768, 3072}).  Why: at d = 768 the operands are served
+// by the L2 (every X column block is re-read by N / 192 output blocks) and the 192 x 192 kernel is bound by its own LDS
+// traffic -- a 48 x 64 wave tile reads (48 + 64) / (48 x 64) fragment bytes per MFMA flop, 1.7 K cycles of LDS
+// bandwidth per stage against 1.15 K cycles of MFMAs; a 96 x 96 wave tile reads 43 % less per flop and a block re-reads
+// dY half as often.  No staging registers (the accumulators take 144 + 24 of the 256): a stage (64 rows of both operands,
+// 72 KB) comes in by LDS-DMA, 9 instructions per wave, with the bank swizzle of the 192-wide kernel applied on the SOURCE
+// side (LDS position p of a slab holds source chunk swz(p): an LDS-DMA instruction writes 64 consecutive 16-B slots).
+// bf16 only, no LayerNorm operand (lists that need either stay on wgrad_group_kernel).
+// =========================================================================================
+constexpr int WW_BK = 384, WW_TH = 512;
+
+__global__ __launch_bounds__(WW_TH) void wgrad_wide_kernel(WgArgs a) {
+  using T = bf16;
+  using LY = WgLayout<bf16>;
+  constexpr int RPS = 64, YLD = WG_BLK, XLD = WW_BK;
+  constexpr int YSLAB = RPS * YLD, XSLAB = RPS * XLD, STG = YSLAB + XSLAB;   // elements per stage: 72 KB
+  constexpr int YI = YSLAB / 512, XI = XSLAB / 512, NI = (YI + XI) / 8;      // LDS-DMA instructions: 24 + 48, 9 per wave
+  static_assert((YI + XI) % 8 == 0, "instructions per wave");
+  __shared__ __attribute__((aligned(1024))) T sm[2 * STG];
+
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 2, wk = wave & 3;
+
+  struct Cur { const T* dY; const T* X; float* dW; float* dbias; int M, N, K, n0, k0, stage, stages; };
+  auto decode = [&](int u, Cur& s) {
+    int pi = 0;
+    for (int i = 1; i < a.nprob; ++i) pi = (u >= a.p[i].unit0) ? i : pi;
+    const WgProb& P = a.p[pi];
+    const int ub = u - P.unit0, blk = ub / P.stages;
+    s.dY = reinterpret_cast<const T*>(P.dY); s.X = reinterpret_cast<const T*>(P.X); s.dW = P.dW; s.dbias = P.dbias;
+    s.M = P.M; s.N = P.N; s.K = P.K; s.stages = P.stages;
+    s.stage = ub - blk * P.stages;
+    s.n0 = (blk % P.nbn) * WG_BLK;
+    s.k0 = (blk / P.nbn) * WW_BK;
+  };
+  // source chunk of LDS slot (row r, 16-B slot cl) of a slab: the swizzle of WgLayout<bf16>::chunk is an involution
+  auto swz = [](int r, int cl) { return ((((cl >> 1) ^ (((r >> 1) & 1) | (((r >> 3) & 1) << 1))) << 1) | (cl & 1)); };
+  static_assert(YI == 24 && XI == 48, "instruction j of a wave: j < 3 -> dY slab, else X slab");
+  const unsigned sm_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)sm;
+  auto dma = [&](const Cur& s, int buf) {
+    const int mb = s.stage * RPS;
+    // (the slot -> (row, chunk) divisions are loop-invariant: hoisted, their 18 results lived through the stage loop and
+    //  were spilled -- and a scratch reload between two LDS-DMA instructions is a vmcnt(0) wait.  Recomputed per stage.)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int q = wave + 8 * j;              // wave-uniform
+      const T* src;
+      if (j < 3) {
+        const int p = q * 64 + ln, r = p / (YLD / 8), cl = p % (YLD / 8);
+        src = s.dY + (size_t)min(mb + r, s.M - 1) * s.N + s.n0 + swz(r, cl) * 8;
       } else {
-        R = a.nranges;
-        gb = a.full_rounds * G + idx / R;
-        rng = idx % R;
+        const int p = (q - YI) * 64 + ln, r = p / (XLD / 8), cl = p % (XLD / 8);
+        src = s.X + (size_t)min(mb + r, s.M - 1) * s.K + s.k0 + swz(r, cl) * 8;
       }
-      if (gb >= a.total_blocks) continue;
-      int pi = 0, b0 = 0;
-      for (int i = 0; i < a.nprob; ++i) {
-        const int nb = a.p[i].nbn * ((a.p[i].K + WG_BLK - 1) / WG_BLK);
-        if (gb >= b0 + nb) { b0 += nb; pi = i + 1; } else break;
-      }
-      const WgProb& P = a.p[pi];
-      const int spr = (P.stages + R - 1) / R;
-      const int ub = P.unit0 + (gb - b0) * P.stages;
-      const int u0 = ub + min(P.stages, rng * spr), uend = ub + min(P.stages, (rng + 1) * spr);
-      if (u0 < uend) run(u0, uend);
+      // (inline asm: behind the builtin hipcc puts an s_waitcnt vmcnt(0) before the next read of `sm` -- the prefetch of
+      //  stage u + 1 would be waited out before stage u's first MFMA.  The waits are placed by hand in run().)
+      const unsigned dst = sm_lds + (unsigned)(buf * STG + q * 512) * 2;      // LDS byte address, wave-uniform
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
     }
-    return;
-  }
-  int u0, uend;
-  if (a.use_table == 1) {
-    const unsigned ent = a.table[blockIdx.x];
-    if (ent == 0xFFFFu) return;
-    const WgProb& P = a.p[ent >> 11];
-    const int blk = (int)((ent >> 5) & 0x3Fu), rng = (int)(ent & 0x1Fu);
-    const int spr = (P.stages + a.nranges - 1) / a.nranges;
-    u0 = P.unit0 + blk * P.stages + min(P.stages, rng * spr);
-    uend = P.unit0 + blk * P.stages + min(P.stages, (rng + 1) * spr);
-  } else {
-    u0 = blockIdx.x * a.units_per_wg;
-    uend = min(a.total_units, u0 + a.units_per_wg);
-  }
-  if (u0 >= uend) return;
-  run(u0, uend);
+  };
+
+  // bias gradient (column sums of dY, off the matrix core like the 192-wide kernel): the six n tiles of a wave row are
+  // shared out over its waves wk = 0, 1, 2 (two tiles each) -- six tiles on wave 0 alone were 24 registers nobody has
+  f32x4 acc[6][6], accb[2];
+  auto clear = [&]() {
+    accb[0] = accb[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+      for (int kt = 0; kt < 6; ++kt) acc[nt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  Frag<T> ones;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) ones.v[t] = from_f32<T>(1.0f);
+
+  auto compute = [&](int buf, bool bias) {
+    const T* sY = sm + buf * STG;
+    const T* sX = sY + YSLAB;
+#pragma unroll
+    for (int cs = 0; cs < 2; ++cs) {
+      const int rb0 = cs * 32 + 8 * g, rb1 = rb0 + 4;
+      __builtin_amdgcn_sched_barrier(0);       // (fragments of one K32 chunk at a time: 9 live, not 18)
+      Frag<T> fy[6];
+#pragma unroll
+      for (int nt = 0; nt < 6; ++nt) fy[nt] = LY::tr_ld<YLD>(sY, rb0, rb1, wn * 96 + 16 * nt);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        Frag<T> fx[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) fx[t] = LY::tr_ld<XLD>(sX, rb0, rb1, wk * 96 + 16 * (3 * h + t));
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) mma(fy[nt], fx[t], acc[nt][3 * h + t]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (bias) {  // column sums of dY on the matrix core: dY^T . 1 (this wave's two tiles: wave-uniform choice)
+        if (wk == 0) { mma(fy[0], ones, accb[0]); mma(fy[1], ones, accb[1]); }
+        else if (wk == 1) { mma(fy[2], ones, accb[0]); mma(fy[3], ones, accb[1]); }
+        else { mma(fy[4], ones, accb[0]); mma(fy[5], ones, accb[1]); }
+      }
+    }
+  };
+  auto flush = [&](const Cur& s, bool bias) {
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gn = s.n0 + wn * 96 + 16 * nt + 4 * g + r;
+        float* row = s.dW + (size_t)gn * s.K + s.k0 + wk * 96 + c;
+#pragma unroll
+        for (int kt = 0; kt < 6; ++kt) atomicAdd(row + 16 * kt, acc[nt][kt][r]);
+      }
+    if (bias && c == 0) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(s.dbias + s.n0 + wn * 96 + 16 * (2 * wk + t) + 4 * g + r, accb[t][r]);
+    }
+    clear();
+  };
+
+  bool first_run = true;
+  auto run = [&](int u0, int uend) {
+    if (!first_run) __syncthreads();   // the previous run's last stage may still be read by a slower wave
+    first_run = false;
+    Cur cur, nxt;
+    decode(u0, cur);
+    dma(cur, 0);
+    clear();
+    for (int u = u0; u < uend; ++u) {
+      const int buf = (u - u0) & 1;
+      __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's pieces of stage u (and any flush before them)
+      __syncthreads();                         // everybody's pieces; everybody has left the other buffer
+      if (cur.stage * RPS + RPS > cur.M) {     // the block's last, partial stage: dY rows past M contribute nothing
+        const int first = cur.M - cur.stage * RPS;   // rows [first, 64) of the dY slab
+        T* sY = sm + buf * STG;
+        for (int q = tid; q < (RPS - first) * (YLD / 8); q += WW_TH)
+          *reinterpret_cast<Chunk16*>(sY + first * YLD + q * 8) = (Chunk16){0u, 0u, 0u, 0u};
+        __syncthreads();
+      }
+      nxt = cur;
+      bool flush_now = (u + 1 == uend);
+      if (u + 1 < uend) {
+        if (cur.stage + 1 < cur.stages) nxt.stage = cur.stage + 1;
+        else { decode(u + 1, nxt); flush_now = true; }
+        dma(nxt, buf ^ 1);                     // in flight under this stage's MFMAs
+      }
+      const bool bias = (cur.dbias != nullptr) && cur.k0 == 0 && wk < 3;
+      compute(buf, bias);
+      if (flush_now) flush(cur, bias);
+      cur = nxt;
+    }
+  };
+  wg_dispatch(a, run);
 }
 
 }  // namespace vitpe
@@ -366,6 +540,8 @@ static int wgrad_cu_count() {
 }
 
 static int wgrad_group_launch(int dtype, const void* problems, int nprob, unsigned long long* census, hipStream_t stream);
+static bool g_wide_ok = true;   // vitpe_debug_set_wgrad_wide(0): eligible lists stay on the 192 x 192 kernel (A/B, tests)
+extern "C" int vitpe_debug_set_wgrad_wide(int on) { g_wide_ok = on != 0; return 0; }
 
 extern "C" int vitpe_wgrad_group(int dtype, const void* problems, int nprob, hipStream_t stream) {
   return wgrad_group_launch(dtype, problems, nprob, nullptr, stream);
@@ -385,6 +561,11 @@ static int wgrad_group_launch(int dtype, const void* problems, int nprob, unsign
   const int RPS = dtype == 1 ? 64 : 32, CHN = dtype == 1 ? 8 : 4;
   WgArgs a{};
   a.census = census;
+  // 192 x 384 blocks (wgrad_wide_kernel) when every problem allows them: bf16, plain X operand, whole blocks
+  bool wide = g_wide_ok && dtype == 1 && census == nullptr && nprob > 0;
+  for (int i = 0; i < nprob; ++i)
+    wide = wide && (pr[i].M == 0 || (pr[i].x_op == 0 && pr[i].N % WG_BLK == 0 && pr[i].K % WW_BK == 0));
+  a.bk = wide ? WW_BK : WG_BLK;
   int units = 0, np = 0;
   for (int i = 0; i < nprob; ++i) {
     const vitpe_wgrad_problem_abi& p = pr[i];
@@ -397,7 +578,7 @@ static int wgrad_group_launch(int dtype, const void* problems, int nprob, unsign
     q.unit0 = units;
     q.nbn = (p.N + WG_BLK - 1) / WG_BLK;
     q.stages = (p.M + RPS - 1) / RPS;
-    const long long nu = (long long)q.nbn * ((p.K + WG_BLK - 1) / WG_BLK) * q.stages;
+    const long long nu = (long long)q.nbn * ((p.K + a.bk - 1) / a.bk) * q.stages;
     VITPE_REQUIRE(units + nu < (1LL << 30));
     units += (int)nu;
   }
@@ -409,7 +590,7 @@ static int wgrad_group_launch(int dtype, const void* problems, int nprob, unsign
   // ---- table mode: (block, row range) per workgroup, operand-sharing blocks co-located on one XCD -----------
   int total_blocks = 0, max_blocks = 0, min_stages = 1 << 30;
   for (int i = 0; i < np; ++i) {
-    const int nb = a.p[i].nbn * ((a.p[i].K + WG_BLK - 1) / WG_BLK);
+    const int nb = a.p[i].nbn * ((a.p[i].K + a.bk - 1) / a.bk);
     total_blocks += nb;
     max_blocks = nb > max_blocks ? nb : max_blocks;
     min_stages = a.p[i].stages < min_stages ? a.p[i].stages : min_stages;
@@ -429,7 +610,7 @@ static int wgrad_group_launch(int dtype, const void* problems, int nprob, unsign
     for (int i = 0; i < WG_TABLE; ++i) a.table[i] = 0xFFFFu;
     for (int r = 0; r < R && fits; ++r)
       for (int i = 0; i < np && fits; ++i) {
-        const int nb = a.p[i].nbn * ((a.p[i].K + WG_BLK - 1) / WG_BLK);
+        const int nb = a.p[i].nbn * ((a.p[i].K + a.bk - 1) / a.bk);
         int x = 0;
         for (int k = 1; k < 8; ++k) x = len[k] < len[x] ? k : x;
         for (int b = 0; b < nb; ++b) {
@@ -494,7 +675,8 @@ static int wgrad_group_launch(int dtype, const void* problems, int nprob, unsign
   // (the census instantiation exists for bf16 operands without the LayerNorm X operand only: anything else would silently
   //  accumulate gradients of the wrong operands)
   if (census != nullptr) VITPE_REQUIRE(!lnx && dtype == 1);
-  if (census != nullptr) hipLaunchKernelGGL((wgrad_group_kernel<bf16, true, false>), dim3(grid), dim3(768), 0, stream, a);
+  if (wide) hipLaunchKernelGGL(wgrad_wide_kernel, dim3(grid), dim3(WW_TH), 0, stream, a);
+  else if (census != nullptr) hipLaunchKernelGGL((wgrad_group_kernel<bf16, true, false>), dim3(grid), dim3(768), 0, stream, a);
   else if (dtype == 1 && lnx) hipLaunchKernelGGL((wgrad_group_kernel<bf16, false, true>), dim3(grid), dim3(768), 0, stream, a);
   else if (dtype == 1) hipLaunchKernelGGL((wgrad_group_kernel<bf16, false, false>), dim3(grid), dim3(768), 0, stream, a);
   else if (lnx) hipLaunchKernelGGL((wgrad_group_kernel<float, false, true>), dim3(grid), dim3(768), 0, stream, a);

@@ -87,8 +87,8 @@ def attention(xn: Tensor, wqkv: Tensor, wproj: Tensor, bproj: Tensor, resid: Opt
               mode: int, grid: int, pe_param: Optional[Tensor], inv_freq: Optional[Tensor], degree: int,
               per_head: bool, cos: Optional[Tensor] = None, sin: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
     """-> (y, a, qkv).  CIFAR geometry: one fused kernel (qkv never leaves the chip, `qkv` is empty; bf16 at N = 65,
-    d = 192, hd = 32: the 32x32-tile kernel); other geometries: qkv Linear (panel GEMM) + the per-(image, head) attention
-    core.  cos / sin: caller-supplied rotary tables ([P, hd/2] or [H, P, hd/2]) used instead of the module's own."""
+    d = 192, hd = 32: the 32x32-tile kernel); bf16 at hd = 64, N = 197: projection + core in one kernel, `qkv` its side output;
+    other geometries: qkv Linear (panel GEMM) + the per-(image, head) attention core.  cos / sin: caller-supplied rotary tables ([P, hd/2] or [H, P, hd/2]) used instead of the module's own."""
     dt = xn.dtype
     B, N, D = xn.shape
     t = _pe_tables(mode, grid, pe_param, inv_freq, degree, per_head, cos, sin)
@@ -98,6 +98,12 @@ def attention(xn: Tensor, wqkv: Tensor, wproj: Tensor, bproj: Tensor, resid: Opt
         else:
             a = K.fused_attention_fwd(xn.contiguous(), K.pack_qkv_weights(wqkv.contiguous(), dt, num_heads), num_heads, t)
         qkv = xn.new_empty(0)
+    elif K.attention_fused64_supported(dt, N, num_heads, D // num_heads):
+        # ViT-B/16 geometry: projection + PE + core in one kernel; the raw projection is its side output (the core
+        # backward reads it)
+        qkv = xn.new_empty((B, N, 3 * D))
+        a = K.attention_fused64_fwd(xn.contiguous(), K.pack_weight_frags(wqkv.contiguous().float(), dt, 64, 0), num_heads, t,
+                                    qkv_out=qkv)
     else:
         qkv = K.linear(xn.contiguous().view(B * N, D), _shadow(wqkv, dt), None, epi=L.EPI_BIAS).view(B, N, 3 * D)
         a = K.attention_core_fwd(qkv, num_heads, t)
