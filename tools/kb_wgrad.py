@@ -38,4 +38,4 @@ for name, M, D, layers in (("CIFAR d=192, 6 layers", 512 * 65, 192, 6), ("ViT-B/
         us = timeit(grp.launch)
         print(f"{name:32s} wide blocks {'on ' if wide else 'off'} {us:8.1f} us = {flop / us / 1e6:6.0f} TF   operands {byts / 1e6:7.0f} MB = "
               f"{byts / us / 1e6:5.2f} TB/s if read once")
-    _lib.debug_lib().vitpe_debug_set_wgrad_wide(1)
+    _lib.debug_lib().vitpe_debug_set_wgrad_wide(0)

@@ -50,6 +50,7 @@ PROBES = {
 FALLBACK = {
     "attn_fwd": [["attn_fwd_kernel"], ["attn_fused64_fwd_kernel"], ["attn_core_fwd_kernel"]],   # (ViT-B/16 geometry: the one-kernel forward, or the core)
     "attn_bwd": [["attn_core_bwd_kernel"]],
+    "wgrad_group": [["wgrad_wide_kernel"]],
     "dgrad_qkv_ln1_bwd": [["gemm_panel_kernel"]],
     "block_tail_bwd": [["block_tail2_bwd_kernel"]],
 }

@@ -90,6 +90,15 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
     const float mean = mean_in[row], rstd = rstd_in[row];
     float xh[MAXC][CHN], g[MAXC][CHN];
     float s1 = 0.f, s2 = 0.f;
+    // the residual rows are requested WITH x and dy (packed, 4 registers per chunk): asked for behind the row reductions
+    // they were a second exposed memory latency per row
+    Chunk16 rres[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int ch = lane + 64 * i;
+      rres[i] = (Chunk16){0u, 0u, 0u, 0u};
+      if (dres != nullptr && ch < nch) rres[i] = *reinterpret_cast<const Chunk16*>(dres + (size_t)row * D + ch * CHN);
+    }
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
       const int ch = lane + 64 * i;
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
         for (int t = 0; t < CHN; ++t) o[t] = rstd * (g[i][t] - s1 - xh[i][t] * s2);
         if (dres != nullptr) {
           float rv[CHN];
-          chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(dres + (size_t)row * D + ch * CHN), rv);
+          chunk_to_f32<T>(rres[i], rv);
 #pragma unroll
           for (int t = 0; t < CHN; ++t) o[t] += rv[t];
         }

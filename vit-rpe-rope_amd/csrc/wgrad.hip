@@ -540,7 +540,11 @@ static int wgrad_cu_count() {
 }
 
 static int wgrad_group_launch(int dtype, const void* problems, int nprob, unsigned long long* census, hipStream_t stream);
-static bool g_wide_ok = true;   // vitpe_debug_set_wgrad_wide(0): eligible lists stay on the 192 x 192 kernel (A/B, tests)
+// OFF by default: on the ViT-B/16 lists the wide kernel is 6 % faster stand-alone (tools/kb_wgrad.py: 1 276 -> 1 200 us) and
+// 8-15 % SLOWER inside the train step (engine lists of 21 / 25 / 28 problems: the placement thresholds below were tuned
+// for 192 x 192 blocks -- 488 wide blocks fall through to stream-K, 672 leave a 62 %-full last window).  Until the
+// placement is retuned for it, vitpe_debug_set_wgrad_wide(1) switches it on (tests, tools/kb_wgrad.py).
+static bool g_wide_ok = false;
 extern "C" int vitpe_debug_set_wgrad_wide(int on) { g_wide_ok = on != 0; return 0; }
 
 extern "C" int vitpe_wgrad_group(int dtype, const void* problems, int nprob, hipStream_t stream) {
