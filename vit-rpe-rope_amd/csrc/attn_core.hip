@@ -183,6 +183,7 @@ __global__ __launch_bounds__(64 * NW) void attn_core_fwd_kernel(AttnArgs a) {
 // =========================================================================================
 // 16-B store of two adjacent [feature][token] accumulator tiles (features 16 nt0 .. 16 nt0 + 31 of the lane's token row):
 // one v_permlane16_swap per dword gives every lane 8 CONTIGUOUS features (as tail2.hip's t2_store_pair)
+template <bool NT = false>
 VITPE_DEV void f64_store_pair(bf16* rowp, int nt0, int g, const f32x4& o0, const f32x4& o1) {
   uint32_t lo[2], hi[2];
 #pragma unroll
@@ -194,7 +195,9 @@ VITPE_DEV void f64_store_pair(bf16* rowp, int nt0, int g, const f32x4& o0, const
     lo[w2] = r[0]; hi[w2] = r[1];
   }
   const Chunk16 v = {lo[0], lo[1], hi[0], hi[1]};
-  *reinterpret_cast<Chunk16*>(rowp + 16 * (nt0 + (g & 1)) + 8 * (g >> 1)) = v;
+  Chunk16* dst = reinterpret_cast<Chunk16*>(rowp + 16 * (nt0 + (g & 1)) + 8 * (g >> 1));
+  if (NT) __builtin_nontemporal_store(v, dst);   // (read again only by a much later kernel)
+  else *dst = v;
 }
 
 constexpr int F64_CW = 7, F64_LW = 2, F64_NW = F64_CW + F64_LW;
@@ -214,7 +217,12 @@ __global__ __launch_bounds__(64 * F64_NW) void attn_fused64_fwd_kernel(AttnArgs 
   __shared__ __attribute__((aligned(16))) float s_coef[KM == KM_POLY ? C::PESZ : 4];
 
   const int N = a.N, H = a.H, Dr = H * HD, P = N - 1;
-  const int b = blockIdx.x / H, hg = blockIdx.x % H;
+  // XCD-aware order: workgroup w runs on XCD w % 8, each with its own L2.  All H heads of an image read the same x rows:
+  // an XCD gets a contiguous eighth of the (image, head) list, so an image's heads share one L2 (in launch order they land
+  // on eight: PMC 257 MB fetched per launch at B = 64 for 97 MB of operands).
+  int wg = (int)blockIdx.x;
+  if ((gridDim.x & 7) == 0) wg = (wg & 7) * (int)(gridDim.x >> 3) + (wg >> 3);
+  const int b = wg / H, hg = wg % H;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 15, g = lane >> 4;
@@ -332,7 +340,7 @@ __global__ __launch_bounds__(64 * F64_NW) void attn_fused64_fwd_kernel(AttnArgs 
 #pragma unroll
       for (int m = 0; m < 3; ++m)
 #pragma unroll
-        for (int j = 0; j < 4; j += 2) f64_store_pair(qo + (size_t)m * Dr, j, g, acc[m][j][tt], acc[m][j + 1][tt]);
+        for (int j = 0; j < 4; j += 2) f64_store_pair<true>(qo + (size_t)m * Dr, j, g, acc[m][j][tt], acc[m][j + 1][tt]);
     }
   }
   // ---- rotation of q and k (rotate-half pairs (f, f + 32): tile j and tile j + 2, same register), class token excluded -----
