@@ -62,6 +62,25 @@ VITPE_DEV Frag<float> ld_rot_frag(const float* rowp, int f0, const float* cs, co
   return f;
 }
 
+// 16-B store of two adjacent [feature][token] accumulator tiles (features 16 nt0 .. 16 nt0 + 31 of the lane's token row):
+// one v_permlane16_swap per dword gives every lane 8 CONTIGUOUS features (as tail2.hip's t2_store_pair)
+template <bool NT = false>
+VITPE_DEV void f64_store_pair(bf16* rowp, int nt0, int g, const f32x4& o0, const f32x4& o1) {
+  uint32_t lo[2], hi[2];
+#pragma unroll
+  for (int w2 = 0; w2 < 2; ++w2) {
+    bf16x2 pa, pb;
+    pa[0] = (bf16)o0[2 * w2]; pa[1] = (bf16)o0[2 * w2 + 1];
+    pb[0] = (bf16)o1[2 * w2]; pb[1] = (bf16)o1[2 * w2 + 1];
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, pa), __builtin_bit_cast(uint32_t, pb), false, false);
+    lo[w2] = r[0]; hi[w2] = r[1];
+  }
+  const Chunk16 v = {lo[0], lo[1], hi[0], hi[1]};
+  Chunk16* dst = reinterpret_cast<Chunk16*>(rowp + 16 * (nt0 + (g & 1)) + 8 * (g >> 1));
+  if (NT) __builtin_nontemporal_store(v, dst);   // (read again only by a much later kernel)
+  else *dst = v;
+}
+
 // rows of one head's matrix -> LDS tile [nrows][LDH]; rows >= N read as zero (token contractions
 // run over the padded tile)
 template <typename T, typename C, bool ROPE>
@@ -157,9 +176,19 @@ __global__ __launch_bounds__(64 * NW) void attn_core_fwd_kernel(AttnArgs a) {
     }
     const float inv = __builtin_amdgcn_rcpf(l);
     if (i < N) {
+      if constexpr (sizeof(T) == 2) {
 #pragma unroll
-      for (int dt = 0; dt < C::NT; ++dt)
-        st4(outp + (size_t)i * Dr + 16 * dt + 4 * g, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+        for (int dt = 0; dt < C::NT; dt += 2) {
+          f32x4 p0 = o[dt], p1 = o[dt + 1];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { p0[r] *= inv; p1[r] *= inv; }
+          f64_store_pair(reinterpret_cast<bf16*>(outp) + (size_t)i * Dr, dt, g, p0, p1);
+        }
+      } else {
+#pragma unroll
+        for (int dt = 0; dt < C::NT; ++dt)
+          st4(outp + (size_t)i * Dr + 16 * dt + 4 * g, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+      }
     }
   }
 }
@@ -181,25 +210,6 @@ __global__ __launch_bounds__(64 * NW) void attn_core_fwd_kernel(AttnArgs a) {
 // in natural order, q~ stays in registers as the B fragments of the wave's two query-tile jobs, which are the jobs
 // of attn_core_fwd_kernel.
 // =========================================================================================
-// 16-B store of two adjacent [feature][token] accumulator tiles (features 16 nt0 .. 16 nt0 + 31 of the lane's token row):
-// one v_permlane16_swap per dword gives every lane 8 CONTIGUOUS features (as tail2.hip's t2_store_pair)
-template <bool NT = false>
-VITPE_DEV void f64_store_pair(bf16* rowp, int nt0, int g, const f32x4& o0, const f32x4& o1) {
-  uint32_t lo[2], hi[2];
-#pragma unroll
-  for (int w2 = 0; w2 < 2; ++w2) {
-    bf16x2 pa, pb;
-    pa[0] = (bf16)o0[2 * w2]; pa[1] = (bf16)o0[2 * w2 + 1];
-    pb[0] = (bf16)o1[2 * w2]; pb[1] = (bf16)o1[2 * w2 + 1];
-    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, pa), __builtin_bit_cast(uint32_t, pb), false, false);
-    lo[w2] = r[0]; hi[w2] = r[1];
-  }
-  const Chunk16 v = {lo[0], lo[1], hi[0], hi[1]};
-  Chunk16* dst = reinterpret_cast<Chunk16*>(rowp + 16 * (nt0 + (g & 1)) + 8 * (g >> 1));
-  if (NT) __builtin_nontemporal_store(v, dst);   // (read again only by a much later kernel)
-  else *dst = v;
-}
-
 constexpr int F64_CW = 7, F64_LW = 2, F64_NW = F64_CW + F64_LW;
 constexpr int F64_PIECES = 24, F64_NBUF = 3;
 
@@ -612,10 +622,20 @@ __global__ __launch_bounds__(64 * NW) void attn_core_bwd_kernel(AttnArgs a) {
       }
     }
     if (i < N) {
+      if constexpr (sizeof(T) == 2) {   // 16-B pieces (lanes of one token pair up: both sides of a swap pass the guard together)
 #pragma unroll
-      for (int dt = 0; dt < C::NT; ++dt)
-        st4(dq + (size_t)i * 3 * Dr + 16 * dt + 4 * g, dqa[dt][0] * a.scale, dqa[dt][1] * a.scale, dqa[dt][2] * a.scale,
-            dqa[dt][3] * a.scale);
+        for (int dt = 0; dt < C::NT; dt += 2) {
+          f32x4 p0 = dqa[dt], p1 = dqa[dt + 1];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { p0[r] *= a.scale; p1[r] *= a.scale; }
+          f64_store_pair(reinterpret_cast<bf16*>(dq) + (size_t)i * 3 * Dr, dt, g, p0, p1);
+        }
+      } else {
+#pragma unroll
+        for (int dt = 0; dt < C::NT; ++dt)
+          st4(dq + (size_t)i * 3 * Dr + 16 * dt + 4 * g, dqa[dt][0] * a.scale, dqa[dt][1] * a.scale, dqa[dt][2] * a.scale,
+              dqa[dt][3] * a.scale);
+      }
     }
   }
   __syncthreads();
@@ -718,10 +738,18 @@ __global__ __launch_bounds__(64 * NW) void attn_core_bwd_kernel(AttnArgs a) {
       }
     }
     if (j < N) {
+      if constexpr (sizeof(T) == 2) {
 #pragma unroll
-      for (int dt = 0; dt < C::NT; ++dt) {
-        st4(dq + Dr + (size_t)j * 3 * Dr + 16 * dt + 4 * g, dka[dt][0], dka[dt][1], dka[dt][2], dka[dt][3]);
-        st4(dq + 2 * Dr + (size_t)j * 3 * Dr + 16 * dt + 4 * g, dva[dt][0], dva[dt][1], dva[dt][2], dva[dt][3]);
+        for (int dt = 0; dt < C::NT; dt += 2) {
+          f64_store_pair(reinterpret_cast<bf16*>(dq) + Dr + (size_t)j * 3 * Dr, dt, g, dka[dt], dka[dt + 1]);
+          f64_store_pair(reinterpret_cast<bf16*>(dq) + 2 * Dr + (size_t)j * 3 * Dr, dt, g, dva[dt], dva[dt + 1]);
+        }
+      } else {
+#pragma unroll
+        for (int dt = 0; dt < C::NT; ++dt) {
+          st4(dq + Dr + (size_t)j * 3 * Dr + 16 * dt + 4 * g, dka[dt][0], dka[dt][1], dka[dt][2], dka[dt][3]);
+          st4(dq + 2 * Dr + (size_t)j * 3 * Dr + 16 * dt + 4 * g, dva[dt][0], dva[dt][1], dva[dt][2], dva[dt][3]);
+        }
       }
     }
   }
