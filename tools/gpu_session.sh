@@ -10,10 +10,10 @@ out=gpurun_out
 mkdir -p $out
 run() {  # name timeout cmd...
   local name=$1 t=$2; shift 2
-  echo "=== $name: $*"
+  echo "=== $name: $*" >&2
   timeout -k 10 $t "$@"
   local rc=$?
-  echo "=== $name rc=$rc"
+  echo "=== $name rc=$rc" >&2
   if [ $rc -eq 124 ] || [ $rc -ge 128 ]; then echo "=== $name was killed: stopping the session"; exit $rc; fi
   return $rc
 }
