@@ -189,12 +189,13 @@ def test_bf16_captured_step_gradients_full_cifar_geometry(tag, extra):
     _captured_step_against_oracle(tag, extra, 16, "bench_path_parity.jsonl")
 
 
-@pytest.mark.parametrize("tag", ["rope-axial", "polynomial"])
+@pytest.mark.parametrize("tag", ["rope-axial", "polynomial", "rope-mixed", "relative"])
 def test_bf16_captured_step_gradients_at_the_benchmark_batch(tag):
     """The same at B = 512, the batch the metric is quoted on: 2080 token tiles over 256 CUs (the nine-tile block-tail
     workgroups and their split ninth tile), two full rounds of the weight-gradient windows at M = 33 280, a chip-full
     of two-image attention workgroups -- every gradient of the captured step against the oracle (rope-axial = BASELINE
-    config 2, polynomial = the mode whose coefficient gradient is the most rounding-sensitive tensor of the model)."""
+    config 2, polynomial = the mode whose coefficient gradient is the most rounding-sensitive tensor of the model, rope-mixed /
+    relative = the modes with per-head learnable frequency / bias-table gradients)."""
     _captured_step_against_oracle(tag, {}, 512, "bench_path_parity.jsonl")
 
 
