@@ -149,6 +149,10 @@ def kernel_records(eng, args, peak_tflops):
 def time_comm(eng, dist, iters=20):
     """Event-timed all-reduce of both gradient buckets as the step issues them (nothing else running)."""
     def once():
+        if getattr(eng, "allpairs", None) is not None:   # VITPE_DDP_ALLPAIRS=1: the exchange the step uses
+            eng.allpairs(eng.flat_g[eng.bucket_off:])
+            eng.allpairs(eng.flat_g[:eng.bucket_off])
+            return
         w1 = dist.all_reduce(eng.flat_g[eng.bucket_off:], op=dist.ReduceOp.SUM, group=eng.pg, async_op=True)
         w2 = dist.all_reduce(eng.flat_g[:eng.bucket_off], op=dist.ReduceOp.SUM, group=eng.pg, async_op=True)
         w1.wait(); w2.wait()
@@ -327,6 +331,7 @@ def main(argv=None):
             "n_ranks_seen": n_ranks_seen, "comm_ms": comm_ms, "overlap_frac": overlap_frac,
             "rccl_max_channels": rccl_channels,      # None = RCCL's own default
             "ddp_graph": (bool(getattr(eng, "ddp_graph", False)) if world > 1 else None),   # all-reduces captured in the step's graph
+            "exchange": (("allpairs" if getattr(eng, "allpairs", None) is not None else "allreduce") if world > 1 else None),
         }
         if dry:
             line["dry_run"] = True

@@ -40,7 +40,15 @@ def _worker(rank, world, port, ret):
     flat_g = torch.zeros(n)
     for k, o in zip(names, offs):
         flat_g[o:o + grads[k].numel()] = grads[k].flatten()
+    alt = flat_g.clone()
     ddp.allreduce_sum_(flat_g)
+    # the all-pairs exchange (all-to-all + local sum + all-gather) must give the same sums, bucket length not a multiple of w
+    ddp.AllPairsSum()(alt)
+    odd = torch.arange(7, dtype=torch.float32) + 10.0 * rank
+    ddp.AllPairsSum()(odd)
+    if rank == 0:
+        ret["allpairs"] = float((alt - flat_g).abs().max() / (flat_g.abs().max() + 1e-30))
+        ret["allpairs_odd"] = float((odd - (2 * torch.arange(7, dtype=torch.float32) + 10.0)).abs().max())
     flat_g *= 1.0 / world                       # what the fused AdamW kernel does via hp[8]
     if rank == 0:
         _, full_loss, full = O.loss_and_grads(cfg, params, images, labels)
@@ -61,3 +69,4 @@ def test_two_rank_gradient_average_equals_global_batch():
         mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
         assert ret["worst"] < 1e-4, ret["worst"]
         assert ret["param_check"] == 0.0
+        assert ret["allpairs"] < 1e-6 and ret["allpairs_odd"] == 0.0, (ret["allpairs"], ret["allpairs_odd"])

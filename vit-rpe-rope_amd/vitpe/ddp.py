@@ -45,6 +45,40 @@ def allreduce_sum_(flat: torch.Tensor, group=None) -> torch.Tensor:
     return flat
 
 
+class AllPairsSum:
+    """SUM of a flat fp32 bucket over all ranks as ONE all-to-all + a local reduction + ONE all-gather: every rank sends
+    chunk j of its bucket straight to rank j (w - 1 concurrent point-to-point transfers -- on a fully connected xGMI mesh
+    one per link), sums the w chunks it received and broadcasts its reduced chunk back the same way.  Two steps of
+    (w - 1) / w of the bucket per rank, against the 2 (w - 1) steps of a ring: the latency-optimal shape for a
+    10-MB bucket on 7 direct links.  Opt-in (VITPE_DDP_ALLPAIRS=1): RCCL's own all-reduce is the
+    default until this has been timed on an 8-GPU node.  Scratch buffers are allocated once per bucket length."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self._scratch = {}
+
+    def __call__(self, flat: torch.Tensor) -> torch.Tensor:
+        if not (dist.is_available() and dist.is_initialized()):
+            return flat
+        w = dist.get_world_size(self.group)
+        if w == 1:
+            return flat
+        n = flat.numel()
+        chunk = (n + w - 1) // w
+        key = (n, flat.device, flat.dtype)
+        if key not in self._scratch:
+            self._scratch[key] = (torch.zeros(w * chunk, dtype=flat.dtype, device=flat.device),
+                                  torch.empty(w * chunk, dtype=flat.dtype, device=flat.device),
+                                  torch.empty(chunk, dtype=flat.dtype, device=flat.device))
+        send, recv, mine = self._scratch[key]
+        send[:n].copy_(flat)                                    # (the padding stays zero)
+        dist.all_to_all_single(recv, send, group=self.group)    # recv[j * chunk:(j + 1) * chunk] = rank j's chunk `rank`
+        torch.sum(recv.view(w, chunk), dim=0, out=mine)
+        dist.all_gather_into_tensor(send, mine, group=self.group)
+        flat.copy_(send[:n])
+        return flat
+
+
 def broadcast_(flat: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat, src=src, group=group)

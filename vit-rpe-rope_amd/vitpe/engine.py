@@ -100,6 +100,12 @@ class TrainEngine:
         self.bucket_off = self._off[id(next(self.model.blocks[self.split_layer].parameters()))] \
             if self.Lyr >= 2 else 0
         self.overlap_comm = self.world > 1 and self.Lyr >= 2
+        # VITPE_DDP_ALLPAIRS=1: the bucket is summed by one all-to-all + a local reduction + one all-gather (every rank
+        # talks to every other rank directly: one transfer per xGMI link) instead of RCCL's all-reduce.  Opt-in until it
+        # has been timed on an 8-GPU node (ddp.AllPairsSum; 2-rank gloo test on CPU)
+        self.allpairs = (ddp.AllPairsSum(self.pg) if self.world > 1 and os.environ.get("VITPE_DDP_ALLPAIRS", "0") == "1"
+                         else None)
+        self._comm_stream = torch.cuda.Stream(device=dev) if self.allpairs is not None else None
         # VITPE_DDP_GRAPH=1: capture the two bucket all-reduces INSIDE the step's HIP graph (bucket 1 on a forked stream
         # beside the lower half of the backward): a step is then ONE replay instead of three replays stitched from the
         # host.  Off by default: RCCL capture has not run on hardware yet (no multi-GPU lease this round either) -- the
@@ -562,7 +568,10 @@ class TrainEngine:
         self.refresh_shadows(cast_flat=False)
 
     def _allreduce(self):
-        ddp.allreduce_sum_(self.flat_g, self.pg)
+        if self.allpairs is not None:
+            self.allpairs(self.flat_g)
+        else:
+            ddp.allreduce_sum_(self.flat_g, self.pg)
 
     # ---------------------------------------------------------------- public API
     def set_valid(self, n_valid: int, n_valid_global: Optional[int] = None):
@@ -743,6 +752,19 @@ class TrainEngine:
                 if self.overlap_comm:
                     # bucket 1 (upper layers + head) is exchanged while the lower layers' backward runs
                     w1 = w2 = None
+                    if exchange and self.allpairs is not None:
+                        # the all-pairs exchange is a composite (all-to-all, local sum, all-gather): bucket 1 on a side
+                        # stream so that the main stream goes on with the lower layers' backward
+                        main = torch.cuda.current_stream()
+                        self._comm_stream.wait_stream(main)
+                        with torch.cuda.stream(self._comm_stream):
+                            self.allpairs(self.flat_g[self.bucket_off:])
+                        self.graph_fb2.replay()
+                        self.allpairs(self.flat_g[:self.bucket_off])
+                        main.wait_stream(self._comm_stream)
+                        self.graph_opt.replay()
+                        self.steps_done += 1
+                        return
                     if exchange:
                         w1 = dist.all_reduce(self.flat_g[self.bucket_off:], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
                     self.graph_fb2.replay()
