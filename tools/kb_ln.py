@@ -19,3 +19,14 @@ for i in range(60): run(i)
 e1.record(); torch.cuda.synchronize()
 t = e0.elapsed_time(e1) / 60 * 1e3
 print(f"ln_bwd M={M} D={D}: {t:.1f} us  {4*M*D*2/t/1e6:.2f} TB/s")
+bt = torch.zeros(D, device="cuda")
+def runf(i):
+    dy, x, m, r, g, dg, db, dres, out = sets[i % 6]
+    K.layernorm_fwd(x, g, bt, out=out, mean=m, rstd=r)
+for i in range(6): runf(i)
+torch.cuda.synchronize()
+e0.record()
+for i in range(60): runf(i)
+e1.record(); torch.cuda.synchronize()
+t = e0.elapsed_time(e1) / 60 * 1e3
+print(f"ln_fwd M={M} D={D}: {t:.1f} us  {2*M*D*2/t/1e6:.2f} TB/s")
