@@ -231,8 +231,8 @@ int vitpe_gemm_tn(int dtype, const void* dY, const void* X, float* dW, float* db
  * reference: vit.py:35,37 and timm Mlp fc1/fc2, once per block).  `problems` is a HOST array; the
  * descriptors travel as kernel arguments (no device table, graph-capture safe).  Work is cut into
  * (192x192 output block, 64-token stage) units spread evenly over the CUs, so each output block is
- * accumulated (fp32 atomics) by only a handful of workgroups.  N, K multiples of 8 (bf16) / 4 (fp32).  (A 192 x 384-block
- * variant for lists with N % 192 == 0, K % 384 == 0 exists behind vitpe_debug_set_wgrad_wide: vitpe_debug.h.)       */
+ * accumulated (fp32 atomics) by only a handful of workgroups.  N, K multiples of 8 (bf16) / 4 (fp32).  Lists whose every
+ * problem has N % 192 == 0 and K % 384 == 0 (bf16, x_op 0: the ViT-B/16 shapes) run on 192 x 384 blocks instead.  */
 typedef struct {
   const void* dY; /* [M,N] T */
   const void* X;  /* [M,K] T */

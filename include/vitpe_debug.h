@@ -43,8 +43,8 @@ int vitpe_debug_tail2_census(const void* attn_out, const void* x_in, const void*
 /* Tile height of the big-tile bf16 GEMM behind vitpe_gemm_nt / vitpe_linear (csrc/gemm2d.hip): 0 = the host's choice per
  * shape, 4 / 5 / 6 = (32 mt)-row tiles for every launch.  Tests and A/B measurements.                                */
 int vitpe_debug_set_gemm2d_mt(int mt);
-/* 1: problem lists that qualify for the 192 x 384-block weight-gradient kernel (bf16, plain X, N % 192 == 0, K % 384 == 0)
- * take it; 0 (default): everything runs on the 192 x 192 kernel.  Tests and A/B measurements (tools/kb_wgrad.py).       */
+/* 0: problem lists that qualify for the 192 x 384-block weight-gradient kernel (bf16, plain X, N % 192 == 0, K % 384 == 0)
+ * stay on the 192 x 192 kernel; 1 (default): they take the wide one.  Tests and A/B measurements (tools/kb_wgrad.py). */
 int vitpe_debug_set_wgrad_wide(int on);
 /* Read-only streaming kernel: `bytes` of src with 16-B loads, `depth` (1 / 4 / 8) independent loads in flight per lane,
  * `workgroups` x 256 threads, grid-stride; writes nothing.  The read ceiling of this box (tools/membw.py).        */

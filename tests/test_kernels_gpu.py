@@ -500,12 +500,10 @@ def test_wgrad_group_wide_blocks(K, case):
         assert sum((N // 192) * (K_ // 384) for _, N, K_, _ in shapes) >= 2 * 256
     from vitpe import _lib as L
     grp = K.WgradGroup(probs)
-    assert L.debug_lib().vitpe_debug_set_wgrad_wide(1) == 0      # (off by default: see csrc/wgrad.hip)
-    try:
-        grp.launch()
-        grp.launch()   # accumulates
-    finally:
-        L.debug_lib().vitpe_debug_set_wgrad_wide(0)
+    assert L.debug_lib().vitpe_debug_set_wgrad_wide(1) == 0      # (the default)
+    grp.launch()
+    grp.launch()   # accumulates
+    snap = [(dw.clone(), None if db is None else db.clone()) for _, _, dw, db in probs]
     for (dy, x, dw, db), (rw, rb) in zip(probs, refs):
         dw *= 0.5
         if db is not None:
@@ -517,6 +515,21 @@ def test_wgrad_group_wide_blocks(K, case):
         assert rel_err(dw[:, -97:].cpu(), rw[:, -97:]) < 2 * tol("bf16")
         if db is not None:
             assert rel_err(db.cpu(), rb) < tol("bf16"), tuple(dw.shape)
+    # the same list on the 192 x 192 kernel (debug switch): same sums up to the order of the fp32 atomics
+    try:
+        L.debug_lib().vitpe_debug_set_wgrad_wide(0)
+        for _, _, dw, db in probs:
+            dw.zero_()
+            if db is not None:
+                db.zero_()
+        grp.launch()
+        grp.launch()
+    finally:
+        L.debug_lib().vitpe_debug_set_wgrad_wide(1)
+    for (dy, x, dw, db), (dw_w, db_w) in zip(probs, snap):
+        assert rel_err(dw.cpu(), dw_w.cpu()) < 1e-4
+        if db is not None:
+            assert rel_err(db.cpu(), db_w.cpu()) < 1e-4
 
 
 def test_wgrad_group_range_major_windows_model_sized_list(K):

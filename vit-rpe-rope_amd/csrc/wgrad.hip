@@ -52,6 +52,7 @@ struct WgArgs {
   int use_table;   // 1: workgroup i runs table[i] = (problem << 11 | block << 5 | row range), 0xFFFF = idle; 2: window mode
   int nranges;     // row ranges per block in table mode (window mode: of the blocks of the last, partial window)
   int full_rounds, total_blocks;   // window mode (use_table == 2): whole windows of gridDim.x blocks; blocks in the list
+  int tail_rounds;                 // ... and the windows its last, partial window's (row range, block) pairs are dealt over
   int bk;          // block width along K: 192 (wgrad_group_kernel) or 384 (wgrad_wide_kernel)
   int range_major; // window mode, lists below two windows: EVERY block is cut into nranges row ranges, the (range, block) pairs
                    // are dealt range-major in full_rounds windows (73 blocks x 7 ranges = 511 of 512 slots: two balanced rounds)
@@ -109,10 +110,10 @@ VITPE_DEV void wg_dispatch(const WgArgs& a, RunFn run) {
   // operands.)  One flush per block; the last, partial window is cut into row ranges so that it still fills the chip.
   if (a.use_table == 2) {
     const int G = gridDim.x, idx = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-    for (int r = 0; r <= a.full_rounds; ++r) {
+    const int nrounds = a.range_major ? a.full_rounds : a.full_rounds + a.tail_rounds;
+    for (int r = 0; r < nrounds; ++r) {
       int gb, rng = 0, R = 1;
       if (a.range_major) {
-        if (r == a.full_rounds) break;
         const int vb = r * G + idx;
         R = a.nranges;
         rng = vb / a.total_blocks;
@@ -120,9 +121,13 @@ VITPE_DEV void wg_dispatch(const WgArgs& a, RunFn run) {
       } else if (r < a.full_rounds) {
         gb = r * G + idx;
       } else {
+        // the blocks left over by the whole windows, each cut into R row ranges; the (range, block) pairs range-major over
+        // tail_rounds windows (adjacent workgroups = adjacent blocks over the same rows, as in a whole window)
         R = a.nranges;
-        gb = a.full_rounds * G + idx / R;
-        rng = idx % R;
+        const int rem = a.total_blocks - a.full_rounds * G, q = (r - a.full_rounds) * G + idx;
+        if (q >= rem * R) continue;
+        rng = q / rem;
+        gb = a.full_rounds * G + q % rem;
       }
       if (gb >= a.total_blocks) continue;
       int pi = 0, b0 = 0;
@@ -540,11 +545,12 @@ static int wgrad_cu_count() {
 }
 
 static int wgrad_group_launch(int dtype, const void* problems, int nprob, unsigned long long* census, hipStream_t stream);
-// OFF by default: on the ViT-B/16 lists the wide kernel is 6 % faster stand-alone (tools/kb_wgrad.py: 1 276 -> 1 200 us) and
-// 8-15 % SLOWER inside the train step (engine lists of 21 / 25 / 28 problems: the placement thresholds below were tuned
-// for 192 x 192 blocks -- 488 wide blocks fall through to stream-K, 672 leave a 62 %-full last window).  Until the
-// placement is retuned for it, vitpe_debug_set_wgrad_wide(1) switches it on (tests, tools/kb_wgrad.py).
-static bool g_wide_ok = false;
+// On by default.  (It first ran SLOWER inside the ViT-B/16 step than stand-alone: the single-GPU step hands over all 49
+// problems as launches of 28 + 21, and the placement below -- tuned for 192 x 192 blocks -- sent the 488 wide blocks of the
+// second launch to stream-K and left the first one a 62 %-full last window.  With equal launches (25 + 24) and the tail of
+// a window list dealt as (row range, block) pairs over several windows: step 11.30 -> 11.11 ms.)
+// vitpe_debug_set_wgrad_wide(0): eligible lists stay on the 192 x 192 kernel (A/B, tests).
+static bool g_wide_ok = true;
 extern "C" int vitpe_debug_set_wgrad_wide(int on) { g_wide_ok = on != 0; return 0; }
 
 extern "C" int vitpe_wgrad_group(int dtype, const void* problems, int nprob, hipStream_t stream) {
@@ -633,22 +639,29 @@ static int wgrad_group_launch(int dtype, const void* problems, int nprob, unsign
     }
   }
   const int G = ncu & ~7;
-  if (!a.use_table && G >= 8 && total_blocks >= 2 * G) {
+  if (!a.use_table && G >= 8 && total_blocks >= G) {
     a.use_table = 2;
     a.total_blocks = total_blocks;
     a.full_rounds = total_blocks / G;
     const int rem = total_blocks - a.full_rounds * G;
-    int Rl = rem > 0 ? G / rem : 1;
-    if (Rl > min_stages / 4) Rl = min_stages / 4;
-    if (Rl > 31) Rl = 31;
-    if (Rl < 1) Rl = 1;
-    a.nranges = Rl;
+    // the leftover blocks in R row ranges over T = ceil(rem R / G) windows: the tail then lasts T / R of a block's time.
+    // Smallest T / R wins, ties go to fewer ranges (fewer partial flushes).  (Round 2 allowed one tail window only, R =
+    // G / rem: 160 leftover blocks of a 672-block list ran as ONE 62 %-full window a whole block long.)
+    int bestR = 1, bestT = rem > 0 ? 1 : 0;
+    int Rmax = min_stages / 4;
+    if (Rmax > 8) Rmax = 8;         // (every range is one more partial flush of the block: fp32 atomics)
+    for (int Rc = 2; rem > 0 && Rc <= Rmax; ++Rc) {
+      const int Tc = (rem * Rc + G - 1) / G;
+      if ((long long)Tc * bestR < (long long)bestT * Rc) { bestR = Rc; bestT = Tc; }
+    }
+    a.nranges = bestR;
+    a.tail_rounds = bestT;
     grid = G;
   }
   // lists below two windows (the CIFAR model: 73 blocks): the same placement on (row range, block) pairs when some R fills
   // k rounds of the chip almost exactly -- co-location cuts the fetched bytes by a third (PMC: 1.77 -> 1.20 GB) as the
   // table mode does, without its second, 71 %-full round
-  if (!a.use_table && G >= 8 && total_blocks > 0 && total_blocks < 2 * G) {
+  if (!a.use_table && G >= 8 && total_blocks > 0 && total_blocks < G) {
     int bestR = 0, bestk = 0;
     double besteff = 0.0;
     for (int k = 1; k <= 3; ++k) {

@@ -475,8 +475,11 @@ class TrainEngine:
             elif part == "lower":
                 hi = self.split_layer - 1
             probs = self._wgrad_problems(lo, hi, part != "upper")
-            self._wg_groups[part] = [K.WgradGroup(probs[i:i + K.WgradGroup.MAX])
-                                     for i in range(0, len(probs), K.WgradGroup.MAX)]
+            # lists above the kernel-argument limit (ViT-B/16: 49 problems) go out as equal launches (25 + 24, not 28 + 21:
+            # the placement of blocks over the chip works per launch)
+            ng = -(-len(probs) // K.WgradGroup.MAX)
+            per = -(-len(probs) // ng)
+            self._wg_groups[part] = [K.WgradGroup(probs[i:i + per]) for i in range(0, len(probs), per)]
         for grp in self._wg_groups[part]:
             grp.launch()
 
