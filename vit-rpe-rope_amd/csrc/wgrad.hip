@@ -78,7 +78,11 @@ template <> struct WgLayout<bf16> {
     const int i = threadIdx.x & 15, q = i >> 2, p = i & 3;
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     const int r0 = rb0 + q, r1 = rb1 + q;
-    const int s0 = ((r0 >> 1) & 1) | (((r0 >> 3) & 1) << 1), s1 = ((r1 >> 1) & 1) | (((r1 >> 3) & 1) << 1);
+    // rows of 384 B alternate between the two halves of the banks by themselves; rows that are a multiple of 256 B (LD = 384
+    // elements) all start on bank 0: the swizzle then also flips the 128-B half with the row's parity (PMC on the first
+    // version of the wide kernel: 33 % of the LDS cycles were bank conflicts)
+    constexpr int PAR = (LD % 128 == 0) ? 4 : 0;
+    const int s0 = (((r0 >> 1) & 1) | (((r0 >> 3) & 1) << 1)) ^ ((r0 & 1) * PAR), s1 = (((r1 >> 1) & 1) | (((r1 >> 3) & 1) << 1)) ^ ((r1 & 1) * PAR);
     const bf16* a0 = tile + r0 * LD + (((c0 >> 4) ^ s0) << 4) + 4 * p;
     const bf16* a1 = tile + r1 * LD + (((c0 >> 4) ^ s1) << 4) + 4 * p;
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
@@ -393,6 +397,9 @@ __global__ __launch_bounds__(WW_TH) void wgrad_wide_kernel(WgArgs a) {
   };
   // source chunk of LDS slot (row r, 16-B slot cl) of a slab: the swizzle of WgLayout<bf16>::chunk is an involution
   auto swz = [](int r, int cl) { return ((((cl >> 1) ^ (((r >> 1) & 1) | (((r >> 3) & 1) << 1))) << 1) | (cl & 1)); };
+  auto swzx = [](int r, int cl) {   // X slab (768-B rows): + the row-parity flip of the 128-B half (WgLayout<bf16>::tr_ld)
+    return ((((cl >> 1) ^ ((((r >> 1) & 1) | (((r >> 3) & 1) << 1)) ^ ((r & 1) << 2))) << 1) | (cl & 1));
+  };
   static_assert(YI == 24 && XI == 48, "instruction j of a wave: j < 3 -> dY slab, else X slab");
   const unsigned sm_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)sm;
   auto dma = [&](const Cur& s, int buf) {
@@ -410,7 +417,7 @@ __global__ __launch_bounds__(WW_TH) void wgrad_wide_kernel(WgArgs a) {
         src = s.dY + (size_t)min(mb + r, s.M - 1) * s.N + s.n0 + swz(r, cl) * 8;
       } else {
         const int p = (q - YI) * 64 + ln, r = p / (XLD / 8), cl = p % (XLD / 8);
-        src = s.X + (size_t)min(mb + r, s.M - 1) * s.K + s.k0 + swz(r, cl) * 8;
+        src = s.X + (size_t)min(mb + r, s.M - 1) * s.K + s.k0 + swzx(r, cl) * 8;
       }
       // (inline asm: behind the builtin hipcc puts an s_waitcnt vmcnt(0) before the next read of `sm` -- the prefetch of
       //  stage u + 1 would be waited out before stage u's first MFMA.  The waits are placed by hand in run().)
