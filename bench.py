@@ -98,35 +98,6 @@ def timed_rotating(fns, rounds):
     return e0.elapsed_time(e1) / (rounds * len(fns))
 
 
-def timed_in_context(fns, before, rounds):
-    """Average duration (ms) of `fns[l]` when each launch follows the kernel that precedes it in the train step
-    (`before[l]`, untimed): event pairs around every timed launch on the launch stream.  The forward attention kernel runs
-    8-20 % slower behind the block-tail kernel of the previous layer than back to back with itself (DESIGN.md, round-3
-    log); this is the duration the step sees, and the one the committed kernel trace shows."""
-    n = len(fns)
-
-    def passes(timed):
-        for l in range(n):
-            before[l](); fns[l]()
-        torch.cuda.synchronize()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(rounds * n)]
-        k = 0
-        for _ in range(rounds):
-            for l in range(n):
-                before[l]()
-                ev[k][0].record()
-                if timed:
-                    fns[l]()
-                ev[k][1].record()
-                k += 1
-        torch.cuda.synchronize()
-        return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
-
-    # an event pair with nothing between costs a few microseconds by itself (the second event's own packet): the same passes
-    # with an empty interval are the zero of the scale
-    return passes(True) - passes(False)
-
-
 def load_pmc():
     """Newest committed profiles/r*_pmc.json: {"commit", "entries": {"<probe>|B<batch>|<mode>|<dtype>": {...}}}."""
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_pmc.json")))
@@ -147,9 +118,6 @@ def kernel_records(eng, args, peak_tflops):
     for pr in eng.kernel_probes():
         rounds = max(3, 120 // len(pr["fns"]))
         ms = timed_rotating(pr["fns"], rounds)
-        ms_b2b = None
-        if pr.get("before"):      # the headline kernel: timed behind its in-step predecessor; the back-to-back figure rides along
-            ms_b2b, ms = ms, timed_in_context(pr["fns"], pr["before"], rounds)
         ai = pr["flop"] / pr["bytes"]
         roof_tf = min(peak_tflops, HBM_PEAK_GBS * 1e9 * ai / 1e12)
         tf = pr["flop"] / (ms * 1e-3) / 1e12
@@ -173,10 +141,6 @@ def kernel_records(eng, args, peak_tflops):
             for k in ("mfma_pipe_busy_frac", "lds_bank_conflict_frac"):
                 if k in ent:
                     rec[k] = ent[k]
-        if ms_b2b is not None:
-            rec["launch_ms_back_to_back"] = round(ms_b2b, 5)
-            rec["timing"] = ("HIP events around every launch, each behind the kernel that precedes it in the train step, minus the "
-                             "same event pairs around nothing")
         recs.append(rec)
     eng.flat_g.zero_()
     return recs

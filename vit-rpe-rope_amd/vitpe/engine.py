@@ -828,15 +828,6 @@ class TrainEngine:
                                " (fused LN1+QKV-project+RoPE+QK^T+softmax+AV)",
                                fns=[fwd(l) for l in range(self.Lyr)], flop=qkv_flop + attn_core_flop,
                                bytes=2 * M * D * es))           # x in, merged heads out (49 920 B / image)
-            if self.tail2 and self.fuse_ln:
-                # what runs in front of layer l's attention in the step: the block tail of layer l - 1 (layer 0: of the last
-                # layer -- same kernel, same sizes); bench.py times the attention launches behind it
-                def tail_before(l):
-                    lp = (l - 1) % self.Lyr
-                    blk, a = mdl.blocks[lp], self.act[lp]
-                    nxt = (self.act[lp + 1]["m1"], self.act[lp + 1]["r1"]) if lp + 1 < self.Lyr else None
-                    return lambda: self._block_tail_fwd(lp, blk, a, nxt, save=True)
-                probes[-1]["before"] = [tail_before(l) for l in range(self.Lyr)]
             if not self.fuse_ln:
                 probes[-1]["kernel"] = probes[-1]["kernel"].replace("fused LN1+", "fused ")
             probes.append(dict(name="attn_bwd", kernel="attn_bwd_kernel (recompute + dQ/dK/dV + PE gradients -> d_qkv)",
