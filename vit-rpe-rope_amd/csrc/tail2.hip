@@ -87,6 +87,10 @@ VITPE_DEV float t2_xg_sum(float v) {
 // Output rows are written with BUFFER stores: (descriptor of the workgroup's rows of the tensor, byte offset of the lane's
 // row) instead of a pointer, so that the cache policy of every tensor is a compile-time choice (`aux`: 0 = write-back L2,
 // 2 = nt, 16 = sc1: written through the L2 as it goes, nothing left for the end-of-kernel write-back).
+#ifndef T2_LOADER_PRIO
+#define T2_LOADER_PRIO 3  // s_setprio of the LDS-DMA loader waves: they share SIMDs 1 and 2 with two compute waves each, and a
+                          // slab issued late is a slab every compute wave waits for (A/B at 0: step 1.523 -> 1.501 ms)
+#endif
 #ifndef T2_AUX_HID
 #define T2_AUX_HID 2      // h, g', LayerNorm2 output, du: read again by a LATER kernel only (weight gradients / backward)
 #endif
@@ -353,6 +357,7 @@ __global__ __launch_bounds__(T2F_THREADS) void block_tail2_fwd_kernel(Tail2Args 
   // left it.  The compute waves never wait for each other, so the waves of a SIMD drift apart and one's MFMAs run under
   // another's GELU.
   if (wave == T2_WAVES || wave == T2_WAVES + 1) {
+    __builtin_amdgcn_s_setprio(T2_LOADER_PRIO);
     const bool is1 = wave == T2_WAVES;                 // fc1 halves : fc2 halves
     const int first = is1 ? 0 : 1, last = is1 ? nchunk - 1 : nchunk;
     const T* const src = is1 ? reinterpret_cast<const T*>(a.w1) : reinterpret_cast<const T*>(a.w2) - (size_t)T2_HALF * 512;
@@ -798,6 +803,7 @@ __global__ __launch_bounds__(T2_THREADS) void block_tail2_bwd_kernel(Tail2BwdArg
   // A slab may be issued once slab g - 3 has been consumed by every active wave (sDone[g - 2]).  When everything has
   // been consumed both load their half of attn.proj.weight^T into fragments [0, 72).
   if (wave >= T2_WAVES) {
+    __builtin_amdgcn_s_setprio(T2_LOADER_PRIO);
     const bool is1 = wave == T2_WAVES;
     const int nq = is1 ? Q : QB, njobs = nq + nchunk;
     const int half = is1 ? 0 : T2_HALF;
@@ -1044,6 +1050,7 @@ __global__ __launch_bounds__(T2_THREADS) void ln_bwd2_kernel(LnBwd2Args a) {
   for (int i = threadIdx.x; i < D; i += T2_THREADS) sGam[i] = a.gamma[i];
 
   if (wave >= T2_WAVES) {      // loaders: half a slab each (36 pieces), slab s -> buffer s & 1
+    __builtin_amdgcn_s_setprio(T2_LOADER_PRIO);
     const int half = wave == T2_WAVES ? 0 : SLF / 2;
     auto dma_half = [&](int sl) {
 #pragma unroll
