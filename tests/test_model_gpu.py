@@ -180,6 +180,59 @@ def test_attention_uses_the_callers_rotary_tables():
             att(x.cuda().to(dt), freqs_cis=(cos.cuda()[:, :-1], sin.cuda()[:, :-1]))
 
 
+@pytest.mark.parametrize("mode", ["rope-axial", "relative"])
+def test_attention_module_bf16_at_the_vit_b16_geometry(mode):
+    """The drop-in Attention module in bf16 at N = 197, hd = 64 (12 heads): torch.ops.vitpe.attention takes the one-kernel
+    forward (qkv projection + PE + core; the raw projection is its side output) and the attention-core backward on it --
+    output and every gradient (x, qkv / proj weights, PE parameters) against the oracle's attention on the bf16-rounded
+    operands."""
+    from models.vit import Attention
+    from models import positional_encoding as pe
+    from vitpe import kernels as K
+    D, H, N, B, bf = 768, 12, 197, 2, torch.bfloat16
+    hd = D // H
+    assert K.attention_fused64_supported(bf, N, H, hd)
+    att = Attention(D, num_heads=H)
+    pos = pe.RoPEAxial(hd, 100.0) if mode == "rope-axial" else pe.RelativePositionalEncoding(N - 1, num_heads=H)
+    att.set_pos_encoding(pos)
+    gen = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        att.qkv.weight.copy_(torch.randn(3 * D, D, generator=gen) * 0.06)
+        att.proj.weight.copy_(torch.randn(D, D, generator=gen) * 0.05)
+        att.proj.bias.copy_(torch.randn(D, generator=gen) * 0.1)
+        if mode == "relative":
+            pos.relative_position_bias_table.copy_(torch.randn(pos.relative_position_bias_table.shape, generator=gen) * 0.5)
+    att.cuda()
+    x = torch.randn(B, N, D, generator=gen)
+    dy = torch.randn(B, N, D, generator=gen)
+    xd = x.cuda().to(bf).requires_grad_(True)
+    if mode == "rope-axial":   # (the block hands the tables over: reference vit.py:121, 51-64)
+        y = att(xd, freqs_cis=pos.cuda().get_freqs_cis(N - 1, torch.device("cuda")))
+    else:
+        y = att(xd)
+    y.backward(dy.cuda().to(bf))
+    # oracle on the rounded operands (fp32 math)
+    rq = lambda t: t.to(bf).float()  # noqa: E731
+    xr = rq(x).requires_grad_(True)
+    wq = rq(att.qkv.weight.detach().cpu()).requires_grad_(True)
+    wp = rq(att.proj.weight.detach().cpu()).requires_grad_(True)
+    qkv = (xr @ wq.t()).reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    if mode == "rope-axial":
+        fc, bias, tab = O.rope_axial_tables(N - 1, O.rope_axial_inv_freq(hd, 100.0)), None, None
+    else:
+        tab = pos.relative_position_bias_table.detach().cpu().clone().requires_grad_(True)
+        fc, bias = None, O.relative_bias(tab, N)
+    o = O.attention_core(qkv[0], qkv[1], qkv[2], hd ** -0.5, fc, bias).transpose(1, 2).reshape(B, N, D)
+    ref = o @ wp.t() + att.proj.bias.detach().cpu()
+    ref.backward(rq(dy))
+    assert rel_err(y.detach().float().cpu(), ref.detach()) < 3e-2
+    assert rel_err(xd.grad.float().cpu(), xr.grad) < 3e-2
+    assert rel_err(att.qkv.weight.grad.cpu(), wq.grad) < 3e-2
+    assert rel_err(att.proj.weight.grad.cpu(), wp.grad) < 3e-2
+    if mode == "relative":
+        assert rel_err(pos.relative_position_bias_table.grad.cpu(), tab.grad) < 3e-2
+
+
 def test_pe_module_api_surface(golden):
     """get_bias / get_freqs_cis / apply_rotary_emb on the drop-in classes (visualizer surface)."""
     from models import positional_encoding as pe
