@@ -240,6 +240,9 @@ def test_config5_twelve_layers_fp32_logits_and_bf16_gradients():
     # a fresh module on the same (bf16-representable) weights for the bf16 engine
     cfg, model = build("rope-axial", {}, IMNET12, seeded=True)
     eng = TrainEngine(model, B, compute_dtype=torch.bfloat16, use_graph=True)
+    assert eng.attn_fused64                     # the one-kernel attention forward is what this geometry runs in bf16
+    # evaluation first (weights untouched): forward without the raw-projection side output (qkv_out = NULL)
+    assert rel_err(eng.forward_only(images.cuda()).cpu(), ref_logits) <= 5e-2
     grads = graph_step_gradients(eng, images.cuda(), labels.cuda())
     assert rel_err(eng.logits.cpu(), ref_logits) <= 5e-2
     report = {}
