@@ -28,6 +28,10 @@
 
 namespace vitpe {
 
+#ifndef T2D_SUPER
+#define T2D_SUPER 1   // supertile order for wide outputs (tile_of); 0: row-panel-major (A/B builds)
+#endif
+
 template <int MT, int EPI>
 __global__ __launch_bounds__(512) void gemm2d_kernel(GemmNTArgs a) {
   typedef bf16 T;
@@ -50,6 +54,20 @@ __global__ __launch_bounds__(512) void gemm2d_kernel(GemmNTArgs a) {
     const int xcd = id & 7, slot = id >> 3;
     const int q = total >> 3, r = total & 7;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    // Wide outputs (more than four column tiles): the tile order inside the run goes by SUPERTILES of 8 row panels x 4
+    // column tiles -- what an XCD's 32 CUs run at one time then needs 8 A panels + 4 W tiles (3.5 MB at K = 768: its L2),
+    // and the next column group finds the A panels still there.  Row-panel-major order put 2.7 panels x ALL column tiles in
+    // flight: the whole weight (4.7 MB at N = 3072) went through every XCD's L2 once per wave of tiles (PMC: 335 MB
+    // fetched + written per fc1 launch for 179 MB of operands).
+    if (T2D_SUPER && (ntn & 3) == 0 && ntn > 4) {
+      constexpr int GH = 8;
+      const int per = GH * ntn, pg = t / per, rr0 = t - pg * per;
+      const int gh = min(GH, ntm - GH * pg);
+      const int cg = rr0 / (gh * 4), rr = rr0 - cg * gh * 4;
+      m0 = (GH * pg + (rr >> 2)) * BM;
+      n0 = (cg * 4 + (rr & 3)) * BN;
+      return;
+    }
     m0 = (t / ntn) * BM;
     n0 = (t % ntn) * BN;
   };
