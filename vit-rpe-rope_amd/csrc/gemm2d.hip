@@ -156,6 +156,9 @@ __global__ __launch_bounds__(512) void gemm2d_kernel(GemmNTArgs a) {
   // epilogue's EP_OPS loads / stores outstanding as well: the stores drain under the first K steps instead of stalling the
   // tile start.  ep_pending is EP_OPS, or 0 for the first tile and after a ragged tile (whose waves skip instructions for
   // rows past M and therefore end their epilogue with vmcnt(0)).
+  // (EPI_BIAS: 2 MT stores; EPI_BIAS_GELU: 4 MT stores; the epilogues with an input operand: 2 MT stores + 2 (MT - 1) row
+  //  loads, two fewer than the constant -- harmless: their last pass has consumed a load YOUNGER than the next tile's
+  //  first stages, so those have retired whatever the count says)
   constexpr int EP_OPS = (EPI == EPI_BIAS ? 1 : 2) * 2 * MT;
   static_assert(EP_OPS + AI + WI < 64, "vmcnt is a 6-bit counter");
   int ep_pending = 0;
