@@ -93,10 +93,11 @@ def test_gemm_nt_gelu_resid_gelubwd(K, dt):
 
 
 @pytest.mark.parametrize("mt", [0, 4, 5, 6])
-@pytest.mark.parametrize("M,N,K_", [(4200, 1024, 192), (2049, 2304, 64), (5000, 1024, 640)])
+@pytest.mark.parametrize("M,N,K_", [(4200, 1024, 192), (2049, 2304, 64), (5000, 1024, 640), (4200, 3072, 128), (2100, 2048, 64)])
 def test_gemm_big_tile_kernel_all_epilogues(K, mt, M, N, K_):
     """csrc/gemm2d.hip (bf16, many rows x wide weights: vitpe_gemm_nt hands these shapes to it) at every tile height, ragged
-    last row tile, one / three / ten K steps, against fp32 math on the bf16-rounded operands."""
+    last row tile, one / three / ten K steps, against fp32 math on the bf16-rounded operands.  N = 3072 / 2048: the wide outputs,
+    whose tiles are walked in supertile order."""
     from vitpe import _lib as L
     assert L.debug_lib().vitpe_debug_set_gemm2d_mt(mt) == 0
     try:
