@@ -24,7 +24,7 @@ def timeit(fn, iters=200, warm=20, rot=1):
 
 def main():
     B = int(os.environ.get("KB_B", "512"))
-    M, D, HID, T, dev = B * 65, 192, 768, torch.bfloat16, "cuda"
+    M, D, HID, T, dev = int(os.environ.get("KB_M", B * 65)), 192, 768, torch.bfloat16, "cuda"   # KB_M=32768: eight tiles on every CU
     ROT = 6   # rotate over per-layer buffers as the step does (no L2 hits on activations across launches)
     g = torch.Generator(device=dev).manual_seed(0)
     r = lambda *s: (torch.rand(*s, device=dev, generator=g) * 2 - 1)  # noqa: E731
