@@ -246,10 +246,17 @@ def main(argv=None):
         eng, dev = DryEngine(dist, world), torch.device("cpu")
         sync = lambda: None  # noqa: E731
     else:
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
+        # VITPE_BENCH_REHEARSAL=gloo: every rank on cuda:0 over gloo -- walks the N > 1 code path (shards, exchange timing, the
+        # report's fields) on a one-GPU box; its numbers mean nothing and the report says so ("rehearsal")
+        rehearsal = world > 1 and os.environ.get("VITPE_BENCH_REHEARSAL", "") == "gloo"
+        dev_index = 0 if rehearsal else local_rank
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
         if world > 1:
-            dist.init_process_group(backend="nccl", device_id=dev)
+            if rehearsal:
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=dev)
         from vitpe.engine import TrainEngine
         from vitpe.vit import VisionTransformer
         torch.manual_seed(0)
@@ -336,6 +343,8 @@ def main(argv=None):
         if dry:
             line["dry_run"] = True
             line["data"] = "none (dry run: launcher / rendezvous / JSON plumbing on CPU ranks over gloo)"
+        elif world > 1 and os.environ.get("VITPE_BENCH_REHEARSAL", "") == "gloo":
+            line["rehearsal"] = "all ranks on cuda:0 over gloo: code-path check only, the numbers mean nothing"
         if recs:
             head = next(r for r in recs if r["name"] == "attn_fwd")
             line["roofline"] = {k: head[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic")}

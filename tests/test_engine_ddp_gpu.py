@@ -107,3 +107,26 @@ def test_two_ranks_on_two_devices_over_rccl():
     two, m2 = _two_ranks("nccl", True, True)
     one, m1 = _one_rank_reference(True)
     _check(two, one, m2, m1)
+
+
+def test_bench_two_rank_code_path_rehearsal():
+    """bench.py's N > 1 path end to end as the driver starts it (torch.distributed.run, one process per rank), with both
+    ranks on cuda:0 over gloo (VITPE_BENCH_REHEARSAL=gloo): sharded batch, exchange timing, max-over-ranks clock, the
+    report's fields.  The numbers mean nothing and the report says so; RCCL itself needs the driver's multi-GPU node."""
+    import json
+    import subprocess
+    port = 29700 + (os.getpid() % 200)
+    env = dict(os.environ, VITPE_BENCH_REHEARSAL="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--no-kernel-probes"], cwd=REPO, env=env, capture_output=True, text=True, timeout=420)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]      # rank 0 prints ONE JSON line
+    rep = json.loads(lines[0])
+    assert rep["n_gpus"] == 2 and rep["n_ranks_seen"] == 2 and rep["config"]["global_batch"] == 2 * rep["config"]["per_gpu_batch"]
+    assert rep["config"]["parallelism"] == "dp2" and rep["scaling"] == "weak" and rep["exchange"] == "allreduce"
+    assert rep["value"] > 0 and rep["comm_ms"] is not None and "rehearsal" in rep
+    assert "cpu_baseline" not in rep                 # rank 0 at N = 1 only
