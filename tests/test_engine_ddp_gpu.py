@@ -115,7 +115,7 @@ def test_bench_two_rank_code_path_rehearsal():
     report's fields.  The numbers mean nothing and the report says so; RCCL itself needs the driver's multi-GPU node."""
     import json
     import subprocess
-    port = 29700 + (os.getpid() % 200)
+    port = 31000 + (os.getpid() % 500)       # disjoint from the ports of _two_ranks
     env = dict(os.environ, VITPE_BENCH_REHEARSAL="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
