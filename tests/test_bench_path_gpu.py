@@ -251,6 +251,29 @@ def test_config5_twelve_layers_fp32_logits_and_bf16_gradients():
     assert not bad, bad
 
 
+def test_config5_bf16_gradients_at_the_benchmark_batch():
+    """Config 5 at the per-GPU batch `bench.py --config imnet` quotes (B = 64, M = 12 608 token rows): only there do the
+    big-tile GEMM with its supertile order (M >= 2048), the 192 x 384 weight-gradient blocks over two equal launches and a
+    chip-full (768 workgroups) of the one-kernel attention forward run inside the captured step -- every gradient against
+    the oracle."""
+    from vitpe.engine import TrainEngine
+    cfg, model = build("rope-axial", {}, IMNET12, seeded=True)
+    params = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+    params["pos_embed.inv_freq"] = model.pos_embed.inv_freq.cpu()
+    B = 64
+    g = torch.Generator().manual_seed(11)
+    images, labels = torch.randn(B, 3, 224, 224, generator=g), torch.randint(0, 10, (B,), generator=g)
+    ref_logits, ref_loss, ref_grads = O.loss_and_grads(cfg, params, images, labels)
+    eng = TrainEngine(model, B, compute_dtype=torch.bfloat16, use_graph=True)
+    assert eng.attn_fused64 and eng.M >= 2048    # (csrc/gemm2d.hip takes the [M, 768] x [N, 768]^T shapes from M = 2048)
+    grads = graph_step_gradients(eng, images.cuda(), labels.cuda())
+    assert rel_err(eng.logits.cpu(), ref_logits) <= 5e-2
+    report = {}
+    bad = compare_all("config5/L12/B64", model, grads, ref_grads, report)
+    _dump(report, "bench_path_parity.jsonl")
+    assert not bad, bad
+
+
 # ------------------------------------------------------------------------------------------------ ragged batches
 SMALL = dict(embed_dim=96, depth=2, num_heads=3)
 
